@@ -1,0 +1,173 @@
+/*
+ * sgp_amd.h -- C ABI of libsgp_amd.so: the MI355X (gfx950) device side of SGP's
+ * training-free spatiotemporal encoder.
+ *
+ * The reference (Graph-Machine-Learning-Group/sgp) is pure Python; the native work on its
+ * hot path is done by third-party ops.  Each entry point below replaces one of
+ * those call sites (paths relative to the reference repo root):
+ *
+ *   sgp_spmm_csr_f32 / sgp_spmm_tiled_f32
+ *       lib/sgp_preprocessing.py:202   `x = adj @ x`
+ *       (torch_sparse SparseTensor.__matmul__ -> spmm_sum(row,rowptr,col,value,colptr,csr2csc,mat))
+ *   sgp_reservoir_f32
+ *       lib/nn/reservoir/reservoir.py:77-81 (ReservoirLayer.forward: 2x F.linear, act, leak)
+ *       driven by the Python time loop at lib/nn/reservoir/reservoir.py:170-183
+ *   sgp_node_mean_bcast_f32
+ *       lib/nn/encoders/sgp_spatial_encoder.py:32-34 (`ones_like(x) * x.mean(-2, keepdim=True)`)
+ *   sgp_copy_rows_f32
+ *       lib/sgp_preprocessing.py:200,217 + sgp_spatial_encoder.py:35 (`torch.cat(out, -1)`) --
+ *       only needed when a caller hands over a tensor that is not already in the
+ *       output slot; the fused path writes slots in place and never concatenates.
+ *   sgp_gather_rows_f32
+ *       lib/datasets/iid_dataset.py:57-99 (IID (t, n) row gather of the embedding; "next" row f1)
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (e.g. the PyTorch
+ *     allocator) unless stated otherwise; nothing is allocated inside.
+ *   - Strides are in ELEMENTS (floats), not bytes.
+ *   - Kernels are enqueued asynchronously on `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream).
+ *   - Every function returns 0 on success, a negative SGP_E* code on a bad
+ *     argument, or a positive hipError_t if the runtime refused the launch.
+ *     Nothing throws.  sgp_last_error() returns a thread-local description.
+ */
+#ifndef SGP_AMD_H
+#define SGP_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGP_ABI_VERSION 1
+
+#define SGP_EINVAL   (-1)  /* bad size / null pointer / misaligned stride */
+#define SGP_EUNSUP   (-2)  /* shape outside what the kernels are built for */
+
+/* activations of lib/nn/reservoir/reservoir.py:37-41 */
+#define SGP_ACT_TANH      0
+#define SGP_ACT_RELU      1
+#define SGP_ACT_SELF_NORM 2
+#define SGP_ACT_IDENTITY  3
+
+typedef void* sgp_stream_t;
+
+int sgp_abi_version(void);
+const char* sgp_last_error(void);
+/* Name of the gfx target the device code was compiled for ("gfx950"). */
+const char* sgp_build_arch(void);
+
+/* ------------------------------------------------------------------ SpMM ---
+ * Y[b, i, 0:feat] = sum_{e in [rowptr[i], rowptr[i+1])} val[e] * X[b, col[e], 0:feat]
+ * for b in [0, batch), i in [0, n_rows).  X and Y may alias the same
+ * allocation as long as the [feat]-wide column ranges do not overlap
+ * (hop k reads slot k-1 and writes slot k of the [T, N, D_out] output).
+ *
+ * Columns >= n_own (when X_halo != NULL) are read from the halo buffer:
+ *   X_halo[b, col - n_own, :]   (rows received from peer GPUs between hops)
+ * Pass X_halo = NULL, n_own = n_cols for the single-GPU case.
+ */
+int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                     const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                     const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                     int32_t n_own,
+                     float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                     int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                     sgp_stream_t stream);
+
+/* LDS-staged variant for graphs with locality.  Rows are grouped into tiles of at most
+ * `tile_rows` consecutive rows (tile k = rows tile_row_ptr[k] .. tile_row_ptr[k+1]); for
+ * tile k the host supplies the sorted list of distinct source rows it references
+ * (ucol[uptr[k] .. uptr[k+1])) and every edge carries the index of its column inside
+ * that list.  Edge lists are padded per row to a multiple of 16 with (lcol = 0, val = 0):
+ *   erow[i] .. erow[i+1]  = padded edge range of row i (multiple of 16 long)
+ *   ecol[e] (uint16)      = index into the tile's ucol list
+ *   eval[e]               = weight
+ * max_union = largest per-tile list length, max_row_edges = largest padded per-row
+ * edge count (host-side facts about the plan; they select the kernel variant).
+ * Returns SGP_EUNSUP if the plan exceeds the limits reported below.
+ */
+int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
+                       const int32_t* erow, const uint16_t* ecol, const float* eval,
+                       int32_t tile_rows, int32_t n_tiles,
+                       int32_t max_union, int32_t max_row_edges,
+                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                       const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                       int32_t n_own,
+                       float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                       sgp_stream_t stream);
+/* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
+ * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and
+ * largest padded per-row edge count. */
+int32_t sgp_spmm_tiled_max_union(int32_t feat);
+int32_t sgp_spmm_tiled_max_tile_rows(void);
+int32_t sgp_spmm_tiled_max_row_edges(void);
+
+/* ------------------------------------------------------------- Reservoir ---
+ * One leaky-ESN layer over the whole sequence (time loop on the device):
+ *   h[t] = (1 - alpha) * h[t-1] + alpha * act(x[t] W_ih^T + b + h[t-1] W_hh^T)
+ * x:   [T, N, F] with strides (x_step_stride, x_row_stride, 1)
+ * out: [T, N, R] with strides (out_step_stride, out_row_stride, 1)
+ * w_ih [R, F], w_hh [R, R], b [R]: row-major device arrays, exactly the
+ *   reference's parameters (lib/nn/reservoir/reservoir.py:43-52).
+ * h_state: optional [N, R] contiguous; if non-NULL it is the initial state and
+ *   receives the final one (T-chunked streaming / resume); NULL = zeros.
+ * workspace: device scratch of sgp_reservoir_workspace_bytes(F, R) bytes
+ *   (weights re-laid out in MFMA fragment order); contents need not persist.
+ * Multi-layer reservoirs (reservoir.py:174-176) are run layer by layer: layer
+ * l > 0 reads layer l-1's slot of the output as its x.
+ */
+int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R);
+int sgp_reservoir_f32(const float* x, int64_t x_row_stride, int64_t x_step_stride,
+                      const float* w_ih, const float* w_hh, const float* b,
+                      double alpha, int32_t act,
+                      float* out, int64_t out_row_stride, int64_t out_step_stride,
+                      float* h_state, void* workspace,
+                      int32_t T, int32_t N, int32_t F, int32_t R,
+                      sgp_stream_t stream);
+
+/* ------------------------------------------------------------ Node mean ----
+ * Y[b, i, 0:feat] = (1 / n_rows) * sum_j X[b, j, 0:feat]   for every i.
+ * With partial != NULL the kernel instead writes the un-normalised column sums
+ * to partial[b, 0:feat] (contiguous) and leaves Y alone (multi-GPU: all-reduce
+ * the partial sums, then call sgp_bcast_rows_f32).
+ */
+int sgp_node_mean_bcast_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                            float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                            float* partial,
+                            int32_t n_rows, int32_t batch, int32_t feat,
+                            sgp_stream_t stream);
+/* Y[b, i, 0:feat] = scale * src[b, 0:feat]  for i in [0, n_rows). */
+int sgp_bcast_rows_f32(const float* src, float scale,
+                       float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                       int32_t n_rows, int32_t batch, int32_t feat,
+                       sgp_stream_t stream);
+
+/* --------------------------------------------------------- Copy / gather ---
+ * Y[b, i, 0:feat] = X[b, i, 0:feat] (strided block copy into an output slot). */
+int sgp_copy_rows_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                      int32_t n_rows, int32_t batch, int32_t feat,
+                      sgp_stream_t stream);
+/* out[k, 0:feat] = X[step[k], node[k], 0:feat]   (IID sampling of the embedding).
+ * Also used to pack halo rows: step = NULL gathers node[k] for every b:
+ *   out[b, k, :] = X[b, node[k], :]. */
+int sgp_gather_rows_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                        const int32_t* step, const int32_t* node, int32_t n_index,
+                        float* out, int64_t out_row_stride, int64_t out_batch_stride,
+                        int32_t batch, int32_t feat, sgp_stream_t stream);
+
+/* -------------------------------------------------------------- Timing -----
+ * HIP-event helpers so that Python can time kernels on the stream they were
+ * launched on without importing a HIP binding. */
+int sgp_event_create(void** ev);
+int sgp_event_destroy(void* ev);
+int sgp_event_record(void* ev, sgp_stream_t stream);
+int sgp_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGP_AMD_H */

@@ -1,0 +1,49 @@
+// ABI bookkeeping, error reporting and HIP-event timing helpers.
+#include "common.h"
+#include <string.h>
+
+namespace sgp {
+static thread_local char g_err[512] = "";
+char* err_buf() { return g_err; }
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+}  // namespace sgp
+
+extern "C" {
+
+int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+const char* sgp_last_error(void) { return sgp::err_buf(); }
+const char* sgp_build_arch(void) { return "gfx950"; }
+
+int sgp_event_create(void** ev) {
+    SGP_REQUIRE(ev != nullptr, "sgp_event_create: null out pointer");
+    hipEvent_t e;
+    hipError_t r = hipEventCreate(&e);
+    if (r != hipSuccess) return sgp::fail((int)r, "hipEventCreate: %s", hipGetErrorString(r));
+    *ev = (void*)e;
+    return 0;
+}
+int sgp_event_destroy(void* ev) {
+    hipError_t r = hipEventDestroy((hipEvent_t)ev);
+    if (r != hipSuccess) return sgp::fail((int)r, "hipEventDestroy: %s", hipGetErrorString(r));
+    return 0;
+}
+int sgp_event_record(void* ev, sgp_stream_t stream) {
+    hipError_t r = hipEventRecord((hipEvent_t)ev, (hipStream_t)stream);
+    if (r != hipSuccess) return sgp::fail((int)r, "hipEventRecord: %s", hipGetErrorString(r));
+    return 0;
+}
+int sgp_event_elapsed_ms(void* start, void* stop, float* ms) {
+    SGP_REQUIRE(ms != nullptr, "sgp_event_elapsed_ms: null out pointer");
+    hipError_t r = hipEventSynchronize((hipEvent_t)stop);
+    if (r == hipSuccess) r = hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop);
+    if (r != hipSuccess) return sgp::fail((int)r, "hipEventElapsedTime: %s", hipGetErrorString(r));
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,27 @@
+// Shared host-side helpers for libsgp_amd.so (gfx950 only; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/sgp_amd.h"
+
+namespace sgp {
+
+char* err_buf();                       // thread-local, 512 bytes
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail((int)e, "%s: %s", what, hipGetErrorString(e));
+    return 0;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+}  // namespace sgp
+
+#define SGP_REQUIRE(cond, ...) \
+    do { if (!(cond)) return sgp::fail(SGP_EINVAL, __VA_ARGS__); } while (0)

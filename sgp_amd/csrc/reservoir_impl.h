@@ -1,0 +1,261 @@
+// Leaky echo-state layer with the whole time loop on the device (reference:
+// lib/nn/reservoir/reservoir.py:77-81 stepped by the Python loop at :170-183).
+//
+//   h[t] = (1-a) h[t-1] + a * act( x[t] W_ih^T + b + h[t-1] W_hh^T )
+//
+// Mapping to gfx950: nodes are independent, time is sequential.  A wave owns NT tiles of 16
+// nodes and keeps their state in registers for all T steps.  The contraction is computed
+// TRANSPOSED on the fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact fp32):
+//     D[j, n] += W[j, k] * hT[k, n]
+// so that the accumulator layout (lane = node n + 16*q, register r  <->  feature 16*jt+4*q+r)
+// is already the B-operand layout the next step needs: k-step (kb, s) of the recurrent part
+// consumes register s of state tile kb directly, with the k order of every 16-block permuted
+// to (4*q + s).  The same permutation is baked into the packed W_hh fragments, so the state
+// never leaves its registers and there is no transpose, shuffle or LDS round trip per step.
+// Weights live in LDS in fragment order (one conflict-free ds_read per MFMA operand); when a
+// layer's weights exceed the LDS they are read in the same order from a global workspace
+// (L2-resident, coalesced 256 B per operand).
+
+#pragma once
+#include "common.h"
+
+namespace sgp_res {
+using sgp::f32x4;
+
+
+// ---- packed layout (floats) ---------------------------------------------------------------
+//   bias  [JT][4 q][4 r]                      = b[16 jt + 4 q + r]
+//   Wx    [JT][NKX][64 lanes]                 = W_ih[16 jt + (l&15)][(l>>4) * NKX + ks]
+//   Wh    [JT][JT kb][64 lanes][4 s]          = W_hh[16 jt + (l&15)][16 kb + 4 (l>>4) + s]
+// (zero where the index runs past R or F).
+__host__ __device__ constexpr long long packed_floats(int JT, int NKX) {
+    return (long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256;
+}
+
+// tanh to ~2 ulp: odd Taylor polynomial below 0.25, 1 - 2/(e^{2|x|}+1) above.
+__device__ __forceinline__ float tanh_f32(float x) {
+    const float a = fabsf(x);
+    const float x2 = x * x;
+    float p = 62.f / 2835.f;
+    p = fmaf(p, x2, -17.f / 315.f);
+    p = fmaf(p, x2, 2.f / 15.f);
+    p = fmaf(p, x2, -1.f / 3.f);
+    p = fmaf(p * x2, x, x);
+    const float e = __expf(2.f * a);
+    const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
+    return a < 0.25f ? p : big;
+}
+
+struct ResArgs {
+    const float* x; long long xrs, xss;
+    const float* wp;                 // packed weights (global workspace)
+    float* out; long long ors, oss;
+    float* h_state;
+    float alpha, one_minus_alpha;
+    int act, T, N, F, R;
+    int tiles_per_wave, n_tiles;
+};
+
+template <int JT, int NKX, int NT, bool WLDS>
+__global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const float* wsrc = a.wp;
+    if constexpr (WLDS) {
+        const int total4 = (int)(packed_floats(JT, NKX) / 4);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wp)[i];
+        __syncthreads();
+        wsrc = lds;
+    }
+    const float* bias = wsrc;
+    const float* wx = wsrc + JT * 16;
+    const float* wh = wx + JT * NKX * 64;
+
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int tile0 = wave * NT;
+    if (tile0 >= a.n_tiles) return;
+
+    int node[NT];
+    bool ok[NT];
+    f32x4 h[NT][JT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        node[i] = (tile0 + i) * 16 + n_in;
+        ok[i] = (tile0 + i) < a.n_tiles && node[i] < a.N;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            h[i][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.h_state && ok[i]) {
+                const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (j0 + r < a.R) h[i][jt][r] = a.h_state[(long long)node[i] * a.R + j0 + r];
+            }
+        }
+    }
+    const bool x_vec = (NKX % 4 == 0) && (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.x) & 15u) == 0);
+    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+
+    for (int t = 0; t < a.T; ++t) {
+        // input operands of this step for all my tiles (issued first; consumed after the
+        // recurrent part so their latency hides under its MFMAs)
+        float xr[NT][NKX];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
+            if (x_vec) {
+#pragma unroll
+                for (int k4 = 0; k4 < NKX / 4; ++k4) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[i] && q * NKX + 4 * k4 < a.F) v = *reinterpret_cast<const f32x4*>(xp + 4 * k4);
+                    xr[i][4 * k4 + 0] = v.x; xr[i][4 * k4 + 1] = v.y;
+                    xr[i][4 * k4 + 2] = v.z; xr[i][4 * k4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks)
+                    xr[i][ks] = (ok[i] && q * NKX + ks < a.F) ? xp[ks] : 0.f;
+            }
+        }
+
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            f32x4 acc[JT];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                acc[jt] = *reinterpret_cast<const f32x4*>(bias + jt * 16 + q * 4);
+            // recurrent part: k-step (kb, s) <-> register s of state tile kb
+#pragma unroll
+            for (int kb = 0; kb < JT; ++kb) {
+                f32x4 wf[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    wf[jt] = *reinterpret_cast<const f32x4*>(wh + ((jt * JT + kb) * 64 + lane) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jt][s], h[i][kb][s], acc[jt], 0, 0, 0);
+                }
+            }
+            // input part
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[(jt * NKX + ks) * 64 + lane], xr[i][ks],
+                                                                   acc[jt], 0, 0, 0);
+            }
+            // activation
+            if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_f32(acc[jt][r]);
+            } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+            } else if (a.act == SGP_ACT_SELF_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss = fmaf(acc[jt][r], acc[jt][r], ss);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize(eps=1e-12)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
+            }
+            // leak + store
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[i][jt][r] = a.one_minus_alpha * h[i][jt][r] + a.alpha * acc[jt][r];
+                const int j0 = 16 * jt + 4 * q;
+                if (ok[i] && j0 < a.R) {
+                    float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
+                    if (o_vec) {
+                        *reinterpret_cast<f32x4*>(op) = h[i][jt];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (j0 + r < a.R) op[r] = h[i][jt][r];
+                    }
+                }
+            }
+        }
+    }
+    if (a.h_state) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[i] && j0 + r < a.R) a.h_state[(long long)node[i] * a.R + j0 + r] = h[i][jt][r];
+            }
+    }
+}
+
+
+constexpr int kLdsLimit = 160 * 1024;
+
+template <int JT, int NKX, int NT>
+int launch_layer(ResArgs a, hipStream_t s) {
+    const long long wbytes = packed_floats(JT, NKX) * 4;
+    a.n_tiles = (a.N + 15) / 16;
+    const int n_waves = (a.n_tiles + NT - 1) / NT;
+    // small problems: one wave per workgroup so every wave gets a CU of its own
+    int wpw = (n_waves + 255) / 256;
+    if (wpw < 1) wpw = 1;
+    if (wpw > 4) wpw = 4;
+    const int grid = (n_waves + wpw - 1) / wpw;
+    if constexpr (packed_floats(JT, NKX) * 4 <= kLdsLimit) {
+        auto kern = reservoir_layer<JT, NKX, NT, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
+        if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)wbytes, s, a);
+    } else {
+        hipLaunchKernelGGL((reservoir_layer<JT, NKX, NT, false>), dim3(grid), dim3(64 * wpw), 0, s, a);
+    }
+    return sgp::check_launch("reservoir_layer");
+}
+
+template <int JT, int NKX>
+int launch_nt(const ResArgs& a, hipStream_t s) {
+    // two tiles per wave once every SIMD already has >= 2 waves of single tiles
+    const int n_tiles = (a.N + 15) / 16;
+    if constexpr (JT * 4 * 2 + NKX * 2 <= 160) {
+        if (n_tiles >= 2048) return launch_layer<JT, NKX, 2>(a, s);
+    }
+    return launch_layer<JT, NKX, 1>(a, s);
+}
+
+template <int JT>
+int launch_nkx(const ResArgs& a, int nkx, hipStream_t s) {
+    switch (nkx) {
+        case 1: return launch_nt<JT, 1>(a, s);
+        case 2: return launch_nt<JT, 2>(a, s);
+        case 4: return launch_nt<JT, 4>(a, s);
+        case 8: return launch_nt<JT, 8>(a, s);
+        case 16: return launch_nt<JT, 16>(a, s);
+        case 32: return launch_nt<JT, 32>(a, s);
+        case 64: return launch_nt<JT, 64>(a, s);
+    }
+    return sgp::fail(SGP_EUNSUP, "reservoir: input size not supported");
+}
+
+
+}  // namespace sgp_res

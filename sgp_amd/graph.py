@@ -1,0 +1,292 @@
+"""Host-side graph preparation: edge list -> normalised graph-shift operator in
+int32 CSR, plus the tile plan the LDS-staged SpMM kernel consumes.
+
+Semantics follow ``lib/sgp_preprocessing.py:67-105`` (``preprocess_adj``) and
+``:177-192, 205-216`` (``sgp_spatial_embedding``) of the reference:
+``A[i, j]`` is the weight of edge ``j -> i`` with ``edge_index[0] = j`` (source)
+and ``edge_index[1] = i`` (target); duplicate edges add; ``set_diag`` replaces
+the diagonal by ones, ``remove_diag`` drops it; rows are normalised by their
+weighted in-degree (``D^-1 A``, zero-degree rows stay zero) or symmetrically
+(``D^-1/2 A D^-1/2``) when ``gcn_norm``.
+
+All of this is one-off work per graph (E <= a few 10^7) and runs on the host
+with torch CPU ops; only the resulting arrays travel to the GPU.
+"""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+def _as_edge_tensors(edge_index, edge_weight):
+    if isinstance(edge_index, np.ndarray):          # sgp_preprocessing.py:73-76
+        edge_index = torch.from_numpy(edge_index)
+        if edge_weight is not None and isinstance(edge_weight, np.ndarray):
+            edge_weight = torch.from_numpy(edge_weight)
+    if not torch.is_tensor(edge_index):
+        raise RuntimeError("Edge index must be (edge_index, edge_weight) tuple "
+                           "or SparseTensor.")          # sgp_preprocessing.py:85-87
+    ei = edge_index.detach().to("cpu", torch.long)
+    ew = None if edge_weight is None else edge_weight.detach().to("cpu", torch.float32)
+    return ei, ew
+
+
+def _coalesce(row, col, val, n):
+    """Sort by (row, col) and add duplicates."""
+    key = row * n + col
+    uniq, inv = torch.unique(key, sorted=True, return_inverse=True)
+    out = torch.zeros(uniq.numel(), dtype=val.dtype).index_add_(0, inv, val)
+    return uniq // n, uniq % n, out
+
+
+class ShiftOperator:
+    """Normalised N x N operator in CSR (int32 indices, fp32 values) on the host,
+    with lazily built per-device copies and tile plans.  ``op @ x`` runs the HIP
+    SpMM for a CUDA tensor ``x[..., N, F]`` (the reference's ``adj @ x``,
+    ``lib/sgp_preprocessing.py:202``)."""
+
+    def __init__(self, rowptr, col, val, num_nodes):
+        self.rowptr = rowptr.to(torch.int32).contiguous()
+        self.col = col.to(torch.int32).contiguous()
+        self.val = val.to(torch.float32).contiguous()
+        self.num_nodes = int(num_nodes)
+        self._dev = {}
+        self._plans = {}
+
+    # ---- construction -----------------------------------------------------
+    @classmethod
+    def from_coo(cls, row, col, val, num_nodes, gcn_norm=False, set_diag=False,
+                 remove_diag=False):
+        n = int(num_nodes)
+        row, col, val = _coalesce(row, col, val, n)
+        if set_diag or remove_diag:                  # set_diag wins (:89-92)
+            keep = row != col
+            row, col, val = row[keep], col[keep], val[keep]
+        if set_diag:
+            idx = torch.arange(n, dtype=torch.long)
+            row, col = torch.cat([row, idx]), torch.cat([col, idx])
+            val = torch.cat([val, torch.ones(n, dtype=val.dtype)])
+            order = torch.argsort(row * n + col)
+            row, col, val = row[order], col[order], val[order]
+        deg = torch.zeros(n, dtype=torch.float32).index_add_(0, row, val)
+        if gcn_norm:                                 # :94-98
+            d = deg.pow(-0.5)
+            d[d == float("inf")] = 0
+            val = d[row] * val * d[col]
+        else:                                        # :99-103
+            d = deg.pow(-1.0)
+            d[d == float("inf")] = 0
+            val = d[row] * val
+        counts = torch.bincount(row, minlength=n)
+        rowptr = torch.zeros(n + 1, dtype=torch.long)
+        rowptr[1:] = torch.cumsum(counts, 0)
+        return cls(rowptr, col, val, n)
+
+    @classmethod
+    def from_edges(cls, edge_index, edge_weight=None, num_nodes=None, gcn_norm=False,
+                   set_diag=False, remove_diag=False, undirected=False, transpose=False):
+        ei, ew = _as_edge_tensors(edge_index, edge_weight)
+        n = int(num_nodes) if num_nodes is not None else (int(ei.max()) + 1 if ei.numel() else 0)
+        if ei.numel() and (int(ei.min()) < 0 or int(ei.max()) >= n):
+            raise ValueError("edge_index out of range for num_nodes")
+        if ew is None:
+            ew = torch.ones(ei.shape[1], dtype=torch.float32)
+        col, row = ei[0], ei[1]                      # "transpose", :80-82
+        if transpose:                                # edge_index[[1, 0]], :207
+            row, col = col, row
+        if undirected:                               # to_undirected, :182-185
+            row, col = torch.cat([row, col]), torch.cat([col, row])
+            ew = torch.cat([ew, ew])
+        return cls.from_coo(row, col, ew, n, gcn_norm=gcn_norm, set_diag=set_diag,
+                            remove_diag=remove_diag)
+
+    # ---- duck-typed accessors (torch_sparse.SparseTensor-like) -------------
+    def size(self, dim):
+        return self.num_nodes
+
+    def sparse_sizes(self):
+        return (self.num_nodes, self.num_nodes)
+
+    def nnz(self):
+        return int(self.col.numel())
+
+    def csr(self):
+        return self.rowptr.long(), self.col.long(), self.val
+
+    def coo(self):
+        counts = (self.rowptr[1:] - self.rowptr[:-1]).long()
+        row = torch.repeat_interleave(torch.arange(self.num_nodes), counts)
+        return row, self.col.long(), self.val
+
+    def to_dense(self):
+        row, col, val = self.coo()
+        a = torch.zeros(self.num_nodes, self.num_nodes, dtype=torch.float32)
+        a.index_put_((row, col), val, accumulate=True)
+        return a
+
+    def max_degree(self):
+        if self.num_nodes == 0:
+            return 0
+        return int((self.rowptr[1:] - self.rowptr[:-1]).max())
+
+    # ---- device side --------------------------------------------------------
+    def device_csr(self, device):
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.rowptr.to(device), self.col.to(device), self.val.to(device))
+        return self._dev[key]
+
+    def tile_plan(self, feat, device, limits=None):
+        """Tile plan for feature width ``feat`` on ``device`` or None when the graph
+        has no exploitable locality (then the generic CSR kernel is used)."""
+        key = (feat % 64 == 0, str(device))
+        if key not in self._plans:
+            plan = None
+            if feat % 64 == 0 and self.nnz() > 0:
+                if limits is None:
+                    from . import hip
+                    limits = hip.tiled_limits(feat)
+                plan = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                       self.num_nodes, **limits)
+                if plan is not None:
+                    plan = plan.to(device)
+            self._plans[key] = plan
+        return self._plans[key]
+
+    def propagate(self, x, y, force=None):
+        """y[b] = A x[b] for strided [B, N, F] CUDA views (no allocation)."""
+        from . import hip
+        plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device)
+        if force == "tiled" and plan is None:
+            raise NotImplementedError("no tile plan for this graph / feature width")
+        if plan is not None:
+            hip.spmm_tiled(plan, x, y)
+        else:
+            rowptr, col, val = self.device_csr(x.device)
+            hip.spmm_csr(rowptr, col, val, x, y)
+        return y
+
+    def __matmul__(self, x):
+        if not torch.is_tensor(x) or x.dim() < 2:
+            raise TypeError("ShiftOperator @ expects a dense tensor [..., N, F]")
+        lead = x.shape[:-2]
+        x3 = x.reshape(-1, x.shape[-2], x.shape[-1])
+        if x3.dtype != torch.float32:
+            x3 = x3.float()
+        if x3.stride(2) != 1:
+            x3 = x3.contiguous()
+        on_cpu = not x3.is_cuda
+        if on_cpu:
+            from . import hip
+            hip.require_gpu()
+            x3 = x3.cuda()
+        y = torch.empty_like(x3, memory_format=torch.contiguous_format)
+        self.propagate(x3, y)
+        if on_cpu:
+            y = y.cpu()
+        return y.reshape(*lead, self.num_nodes, x.shape[-1])
+
+
+@dataclass
+class TilePlan:
+    """Arrays of ``sgp_spmm_tiled_f32`` (include/sgp_amd.h)."""
+    trow: torch.Tensor        # int32 [n_tiles + 1], first row of every tile
+    uptr: torch.Tensor        # int32 [n_tiles + 1]
+    ucol: torch.Tensor        # int32 [sum of per-tile distinct columns]
+    erow: torch.Tensor        # int32 [n_rows + 1], padded edge ranges (multiples of 16)
+    ecol: torch.Tensor        # uint16 as int16 storage [padded nnz]
+    eval: torch.Tensor        # float32 [padded nnz]
+    tile_rows: int            # tallest tile
+    n_tiles: int
+    n_rows: int
+    max_union: int
+    max_row_edges: int
+
+    def to(self, device):
+        return TilePlan(self.trow.to(device), self.uptr.to(device), self.ucol.to(device),
+                        self.erow.to(device), self.ecol.to(device), self.eval.to(device),
+                        self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
+                        self.max_row_edges)
+
+
+def tile_unions(rowptr, col, trow):
+    """Per-tile sorted distinct columns for tiles of consecutive rows
+    ``trow[k] .. trow[k+1]``: returns (uptr, ucol, local index per edge, row of edge)."""
+    n_rows = int(trow[-1])
+    n_tiles = len(trow) - 1
+    deg = np.diff(rowptr).astype(np.int64)
+    row_of_edge = np.repeat(np.arange(n_rows, dtype=np.int64), deg)
+    tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
+    tile_of_edge = tile_of_row[row_of_edge]
+    n_cols = int(col.max()) + 1 if col.size else 1
+    key = tile_of_edge * n_cols + col.astype(np.int64)
+    uniq, inv = np.unique(key, return_inverse=True)
+    utile = uniq // n_cols
+    ucol = (uniq % n_cols).astype(np.int32)
+    uptr = np.zeros(n_tiles + 1, dtype=np.int64)
+    np.add.at(uptr, utile + 1, 1)
+    uptr = np.cumsum(uptr)
+    lcol = inv.astype(np.int64) - uptr[tile_of_edge]
+    return uptr, ucol, lcol, row_of_edge
+
+
+def split_tiles(rowptr, col, n_rows, tile_rows, max_union, min_rows=8):
+    """Uniform tiles of ``tile_rows`` consecutive rows; any tile that references more than
+    ``max_union`` distinct columns is halved until it fits (node orders such as Morton
+    have a few tiles that straddle distant regions).  None if even ``min_rows`` rows do
+    not fit."""
+    trow = np.arange(0, n_rows + tile_rows, tile_rows, dtype=np.int64)
+    trow[-1] = n_rows
+    trow = np.unique(trow)
+    while True:
+        uptr, _, _, _ = tile_unions(rowptr, col, trow)
+        over = np.nonzero(np.diff(uptr) > max_union)[0]
+        if over.size == 0:
+            return trow
+        heights = np.diff(trow)[over]
+        if (heights <= min_rows).any():
+            return None
+        mids = trow[over] + heights // 2
+        trow = np.unique(np.concatenate([trow, mids]))
+
+
+def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
+                    candidates=(128, 64, 32)) -> Optional[TilePlan]:
+    """Tallest tiling whose per-tile working set fits the LDS stage, or None when the
+    graph has no locality to exploit (average tile would stage more than it reuses)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    deg = np.diff(rowptr)
+    if n_rows == 0 or col.size == 0 or max_union <= 0:
+        return None
+    pad_deg = ((deg + 15) // 16) * 16
+    mre = int(pad_deg.max())
+    if mre > max_row_edges:
+        return None
+    for tr in candidates:
+        if tr > max_tile_rows:
+            continue
+        # the 4-rows-per-group x 8-batch kernel variant spills; keep tall tiles for short rows
+        if tr > 64 and mre > 32:
+            continue
+        trow = split_tiles(rowptr, col, n_rows, tr, min(max_union, 65535))
+        if trow is None:
+            continue
+        n_tiles = len(trow) - 1
+        if n_tiles > 1.5 * ((n_rows + tr - 1) // tr) + 1:
+            continue                       # mostly split: a smaller uniform height is better
+        uptr, ucol, lcol, row_of_edge = tile_unions(rowptr, col, trow)
+        mu = int(np.diff(uptr).max())
+        erow = np.zeros(n_rows + 1, dtype=np.int64)
+        erow[1:] = np.cumsum(pad_deg)
+        ecol = np.zeros(int(erow[-1]), dtype=np.uint16)
+        evalv = np.zeros(int(erow[-1]), dtype=np.float32)
+        pos = erow[row_of_edge] + (np.arange(col.size, dtype=np.int64) - rowptr[row_of_edge])
+        ecol[pos] = lcol.astype(np.uint16)
+        evalv[pos] = val
+        return TilePlan(torch.from_numpy(trow.astype(np.int32)),
+                        torch.from_numpy(uptr.astype(np.int32)), torch.from_numpy(ucol),
+                        torch.from_numpy(erow.astype(np.int32)),
+                        torch.from_numpy(ecol.view(np.int16)), torch.from_numpy(evalv),
+                        int(np.diff(trow).max()), n_tiles, int(n_rows), mu, mre)
+    return None

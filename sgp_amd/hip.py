@@ -1,0 +1,325 @@
+"""ctypes binding of ``libsgp_amd.so`` (C ABI declared in ``include/sgp_amd.h``).
+
+The library is the ONLY compute path of this package: there is no CPU
+fallback.  Importing :mod:`sgp_amd` works without it (so host-side logic can be
+tested on a CPU box), but the first call that needs a kernel raises
+``RuntimeError`` if the shared object is missing or no MI355X is visible.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libsgp_amd.so")
+
+c_i32, c_i64, c_f32, c_f64, c_p = (ctypes.c_int32, ctypes.c_int64,
+                                   ctypes.c_float, ctypes.c_double,
+                                   ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/sgp_amd.h one to one
+SIGNATURES = {
+    "sgp_abi_version": (ctypes.c_int, []),
+    "sgp_last_error": (ctypes.c_char_p, []),
+    "sgp_build_arch": (ctypes.c_char_p, []),
+    "sgp_spmm_csr_f32": (ctypes.c_int, [c_p, c_p, c_p,
+                                        c_p, c_i64, c_i64,
+                                        c_p, c_i64, c_i64, c_i32,
+                                        c_p, c_i64, c_i64,
+                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_tiled_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p,
+                                          c_i32, c_i32, c_i32, c_i32,
+                                          c_p, c_i64, c_i64,
+                                          c_p, c_i64, c_i64, c_i32,
+                                          c_p, c_i64, c_i64,
+                                          c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
+    "sgp_spmm_tiled_max_tile_rows": (c_i32, []),
+    "sgp_spmm_tiled_max_row_edges": (c_i32, []),
+    "sgp_reservoir_workspace_bytes": (c_i64, [c_i32, c_i32]),
+    "sgp_reservoir_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
+                                         c_p, c_p, c_p,
+                                         c_f64, c_i32,
+                                         c_p, c_i64, c_i64,
+                                         c_p, c_p,
+                                         c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_node_mean_bcast_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
+                                               c_p, c_i64, c_i64, c_p,
+                                               c_i32, c_i32, c_i32, c_p]),
+    "sgp_bcast_rows_f32": (ctypes.c_int, [c_p, c_f32, c_p, c_i64, c_i64,
+                                          c_i32, c_i32, c_i32, c_p]),
+    "sgp_copy_rows_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+                                         c_i32, c_i32, c_i32, c_p]),
+    "sgp_gather_rows_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i32,
+                                           c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+    "sgp_event_create": (ctypes.c_int, [ctypes.POINTER(c_p)]),
+    "sgp_event_destroy": (ctypes.c_int, [c_p]),
+    "sgp_event_record": (ctypes.c_int, [c_p, c_p]),
+    "sgp_event_elapsed_ms": (ctypes.c_int, [c_p, c_p, ctypes.POINTER(c_f32)]),
+}
+
+ACT_CODES = {"tanh": 0, "relu": 1, "self_norm": 2, "identity": 3}
+
+_lib = None
+
+
+def build(jobs=8, verbose=False):
+    """Compile every HIP source for gfx950 into ``csrc/libsgp_amd.so`` (in-tree)."""
+    out = subprocess.run(["make", "-C", _CSRC, f"-j{jobs}"], capture_output=True,
+                         text=True)
+    if verbose or out.returncode:
+        print(out.stdout[-4000:])
+        print(out.stderr[-4000:])
+    if out.returncode:
+        raise RuntimeError("building libsgp_amd.so failed")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and attach the prototypes (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` (or `make -C sgp_amd/csrc`). sgp_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.sgp_abi_version() != 1:
+        raise RuntimeError("libsgp_amd.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def require_gpu():
+    """The product path needs the HIP library AND a device; fail loudly otherwise."""
+    lib = load()
+    if not torch.cuda.is_available():
+        raise RuntimeError("sgp_amd needs an MI355X (torch.cuda.is_available() is "
+                           "False) and has no CPU fallback")
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load().sgp_last_error().decode()
+        kind = NotImplementedError if rc == -2 else RuntimeError
+        raise kind(f"{what} failed (code {rc}): {msg}")
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _view3(t, name):
+    """[B, N, D] float32 CUDA view with unit feature stride -> (ptr, row_stride, batch_stride)."""
+    if t.dim() != 3 or t.dtype != torch.float32 or not t.is_cuda:
+        raise ValueError(f"{name}: expected a 3-D float32 CUDA tensor, got "
+                         f"{tuple(t.shape)} {t.dtype} {t.device}")
+    if t.shape[2] > 1 and t.stride(2) != 1:
+        raise ValueError(f"{name}: feature stride must be 1")
+    return t.data_ptr(), t.stride(1), t.stride(0)
+
+
+MAX_GRID_BATCH = 65535
+
+
+# ---------------------------------------------------------------- SpMM
+def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
+    """y[b, i, :] = sum_e val[e] x[b, col[e], :] (generic CSR kernel)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    n_rows = rowptr.numel() - 1
+    n_cols = x.shape[1] + (halo.shape[1] if halo is not None else 0)
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, n_cols
+    B, D = x.shape[0], x.shape[2]
+    step = 4 * MAX_GRID_BATCH
+    for b0 in range(0, B, step):
+        nb = min(step, B - b0)
+        _check(lib.sgp_spmm_csr_f32(
+            rowptr.data_ptr(), col.data_ptr(), val.data_ptr(),
+            xp + 4 * b0 * xbs, xrs, xbs,
+            (hp + 4 * b0 * hbs) if hp else None, hrs, hbs, n_own,
+            yp + 4 * b0 * ybs, yrs, ybs,
+            n_rows, n_cols, nb, D, _stream(x)), "sgp_spmm_csr_f32")
+
+
+def spmm_tiled(plan, x, y, halo=None, n_own=None):
+    """Same product through the LDS-staged kernel; ``plan`` from graph.TilePlan.to(device)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
+    _check(lib.sgp_spmm_tiled_f32(
+        plan.trow.data_ptr(), plan.uptr.data_ptr(), plan.ucol.data_ptr(), plan.erow.data_ptr(),
+        plan.ecol.data_ptr(), plan.eval.data_ptr(),
+        plan.tile_rows, plan.n_tiles, plan.max_union, plan.max_row_edges,
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
+        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
+        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_tiled_f32")
+
+
+def tiled_limits(feat):
+    lib = load()
+    return dict(max_union=lib.sgp_spmm_tiled_max_union(feat),
+                max_tile_rows=lib.sgp_spmm_tiled_max_tile_rows(),
+                max_row_edges=lib.sgp_spmm_tiled_max_row_edges())
+
+
+# ---------------------------------------------------------------- reservoir
+def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
+    """One leaky-ESN layer over all T steps: x[T, N, F] -> out[T, N, R] (views allowed)."""
+    lib = require_gpu()
+    xp, xrs, xss = _view3(x, "x")
+    op, ors, oss = _view3(out, "out")
+    T, N, F = x.shape
+    R = w_hh.shape[0]
+    for name, w, shape in (("w_ih", w_ih, (R, F)), ("w_hh", w_hh, (R, R)), ("b", b, (R,))):
+        if tuple(w.shape) != shape or w.dtype != torch.float32 or not w.is_cuda \
+                or not w.is_contiguous():
+            raise ValueError(f"{name}: expected contiguous float32 CUDA {shape}")
+    if out.shape[0] != T or out.shape[1] != N or out.shape[2] != R:
+        raise ValueError("out: expected [T, N, R]")
+    wsb = lib.sgp_reservoir_workspace_bytes(F, R)
+    if wsb < 0:
+        raise NotImplementedError(f"reservoir kernel supports input/hidden sizes <= 256 "
+                                  f"(got F={F}, R={R})")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    if h_state is not None and (tuple(h_state.shape) != (N, R) or not h_state.is_contiguous()):
+        raise ValueError("h_state: expected contiguous [N, R]")
+    _check(lib.sgp_reservoir_f32(
+        xp, xrs, xss, w_ih.data_ptr(), w_hh.data_ptr(), b.data_ptr(),
+        float(alpha), ACT_CODES[activation], op, ors, oss,
+        h_state.data_ptr() if h_state is not None else None, ws.data_ptr(),
+        T, N, F, R, _stream(x)), "sgp_reservoir_f32")
+    return out
+
+
+# ---------------------------------------------------------------- helpers
+def _batched(fn, B):
+    for b0 in range(0, B, MAX_GRID_BATCH):
+        fn(b0, min(MAX_GRID_BATCH, B - b0))
+
+
+def node_mean_bcast(x, y):
+    """y[b, i, :] = mean_j x[b, j, :] for every node i (global_attr block)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    B, N, D = x.shape
+    scratch = torch.empty(min(B, MAX_GRID_BATCH), D, dtype=torch.float32, device=x.device)
+
+    def run(b0, nb):
+        _check(lib.sgp_node_mean_bcast_f32(xp + 4 * b0 * xbs, xrs, xbs, yp + 4 * b0 * ybs,
+                                           yrs, ybs, scratch.data_ptr(), N, nb, D,
+                                           _stream(x)), "sgp_node_mean_bcast_f32")
+    _batched(run, B)
+    return y
+
+
+def node_sums(x):
+    """[B, D] un-normalised column sums (multi-GPU: all-reduce these, then bcast_rows)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    B, N, D = x.shape
+    out = torch.empty(B, D, dtype=torch.float32, device=x.device)
+
+    def run(b0, nb):
+        _check(lib.sgp_node_mean_bcast_f32(xp + 4 * b0 * xbs, xrs, xbs, None, 0, 0,
+                                           out.data_ptr() + 4 * b0 * D, N, nb, D,
+                                           _stream(x)), "sgp_node_mean_bcast_f32")
+    _batched(run, B)
+    return out
+
+
+def bcast_rows(src, scale, y):
+    lib = require_gpu()
+    yp, yrs, ybs = _view3(y, "y")
+    B, N, D = y.shape
+    assert src.is_contiguous() and tuple(src.shape) == (B, D)
+
+    def run(b0, nb):
+        _check(lib.sgp_bcast_rows_f32(src.data_ptr() + 4 * b0 * D, float(scale),
+                                      yp + 4 * b0 * ybs, yrs, ybs, N, nb, D, _stream(y)),
+               "sgp_bcast_rows_f32")
+    _batched(run, B)
+    return y
+
+
+def copy_rows(x, y):
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    B, N, D = x.shape
+
+    def run(b0, nb):
+        _check(lib.sgp_copy_rows_f32(xp + 4 * b0 * xbs, xrs, xbs, yp + 4 * b0 * ybs, yrs, ybs,
+                                     N, nb, D, _stream(x)), "sgp_copy_rows_f32")
+    _batched(run, B)
+    return y
+
+
+def gather_nodes(x, node_index, out=None):
+    """out[b, k, :] = x[b, node_index[k], :] (halo packing)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    B, _, D = x.shape
+    K = node_index.numel()
+    if out is None:
+        out = torch.empty(B, K, D, dtype=torch.float32, device=x.device)
+    op, ors, obs = _view3(out, "out")
+
+    def run(b0, nb):
+        _check(lib.sgp_gather_rows_f32(xp + 4 * b0 * xbs, xrs, xbs, None, node_index.data_ptr(),
+                                       K, op + 4 * b0 * obs, ors, obs, nb, D, _stream(x)),
+               "sgp_gather_rows_f32")
+    _batched(run, B)
+    return out
+
+
+def gather_rows(x, step_index, node_index):
+    """out[k, :] = x[step_index[k], node_index[k], :] (IID sampling of the embedding)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    K, D = node_index.numel(), x.shape[2]
+    out = torch.empty(K, D, dtype=torch.float32, device=x.device)
+    _check(lib.sgp_gather_rows_f32(xp, xrs, xbs, step_index.data_ptr(), node_index.data_ptr(), K,
+                                   out.data_ptr(), D, 0, 1, D, _stream(x)), "sgp_gather_rows_f32")
+    return out
+
+
+class Event:
+    """HIP event on the stream the kernels run on (bench.py roofline timing)."""
+
+    def __init__(self):
+        self._h = c_p()
+        _check(load().sgp_event_create(ctypes.byref(self._h)), "sgp_event_create")
+
+    def record(self, stream=None):
+        s = torch.cuda.current_stream().cuda_stream if stream is None else stream
+        _check(load().sgp_event_record(self._h, s), "sgp_event_record")
+
+    def elapsed_ms(self, end):
+        ms = c_f32()
+        _check(load().sgp_event_elapsed_ms(self._h, end._h, ctypes.byref(ms)),
+               "sgp_event_elapsed_ms")
+        return ms.value
+
+    def __del__(self):
+        try:
+            load().sgp_event_destroy(self._h)
+        except Exception:
+            pass

@@ -1,0 +1,82 @@
+import torch
+from torch import nn
+
+from ... import hip
+from ..reservoir import Reservoir
+from ._args import add_reservoir_args, add_spatial_args
+from .sgp_spatial_encoder import SGPSpatialEncoder
+
+
+class SGPEncoder(nn.Module):
+    """SGP's training-free spatiotemporal encoder, ``lib/nn/encoders/sgp_encoder.py:9-51``:
+    reservoir over time, then K-hop graph-shift propagation over nodes.
+
+    The device path allocates the final ``[T, N, D_out]`` tensor once; the reservoir
+    writes its states straight into block 0, every hop reads one block and writes the next
+    and the global-mean block is filled last -- the ``stack``/``rearrange``/``cat`` copies of
+    the reference (reservoir.py:178-183, sgp_spatial_encoder.py:35) never happen.
+    """
+
+    def __init__(self,
+                 input_size,
+                 reservoir_size,
+                 reservoir_layers,
+                 leaking_rate,
+                 spectral_radius,
+                 density,
+                 input_scaling,
+                 receptive_field,
+                 bidirectional,
+                 alpha_decay,
+                 global_attr,
+                 add_self_loops=False,
+                 undirected=False,
+                 reservoir_activation='tanh'):
+        super(SGPEncoder, self).__init__()
+        self.reservoir = Reservoir(input_size=input_size,
+                                   hidden_size=reservoir_size,
+                                   input_scaling=input_scaling,
+                                   num_layers=reservoir_layers,
+                                   leaking_rate=leaking_rate,
+                                   spectral_radius=spectral_radius,
+                                   density=density,
+                                   activation=reservoir_activation,
+                                   alpha_decay=alpha_decay)
+        self.sgp_encoder = SGPSpatialEncoder(
+            receptive_field=receptive_field,
+            bidirectional=bidirectional,
+            undirected=undirected,
+            add_self_loops=add_self_loops,
+            global_attr=global_attr)
+
+    @property
+    def output_size(self):
+        return self.sgp_encoder.num_blocks() * self.reservoir.output_size
+
+    def encode_device(self, x, ops, out=None):
+        """x[T, N, F] CUDA float32 -> out[T, N, D_out] on the same device."""
+        T, N, _ = x.shape
+        d_h = self.reservoir.output_size
+        if out is None:
+            out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
+        self.reservoir.encode_into(x, out[:, :, :d_h])
+        self.sgp_encoder.encode_into(out, d_h, ops)
+        return out
+
+    def forward(self, x, edge_index, edge_weight):
+        # x : [t n f]
+        dev = x.device
+        ops = self.sgp_encoder.operators(x.size(-2), edge_index, edge_weight)
+        xg = x.float()
+        if not xg.is_cuda:
+            hip.require_gpu()
+            xg = xg.cuda()
+        if xg.stride(2) != 1:
+            xg = xg.contiguous()
+        return self.encode_device(xg, ops).to(dev)
+
+    @staticmethod
+    def add_model_specific_args(parser):
+        add_reservoir_args(parser)
+        add_spatial_args(parser)
+        return parser

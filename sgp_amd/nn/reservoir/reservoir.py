@@ -1,0 +1,187 @@
+"""Leaky echo-state reservoir with the reference's Python surface
+(``lib/nn/reservoir/reservoir.py``) and a HIP time loop underneath.
+
+Weights are drawn on the host from the global torch RNG in exactly the
+reference's order (``reservoir.py:54-75``) so a seed reproduces the reference's
+parameters; the recurrence itself runs in ``sgp_reservoir_f32`` (one launch per
+layer, the whole sequence on the device).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import hip
+
+_ACTIVATIONS = ['tanh', 'relu', 'self_norm', 'identity']
+
+
+def _check_activation(activation):
+    # reservoir.py:37 asserts membership, then :41 resolves the name through
+    # tsl.nn.utils.get_functional_activation (tsl/nn/utils/utils.py:34-44),
+    # which knows 'linear' but not 'identity' and raises ValueError for it.
+    assert activation in _ACTIVATIONS
+    if activation == 'identity':
+        raise ValueError(f"Activation '{activation}' not valid.")
+
+
+class ReservoirLayer(nn.Module):
+    def __init__(self,
+                 input_size,
+                 hidden_size,
+                 spectral_radius,
+                 leaking_rate,
+                 bias=True,
+                 density=1.,
+                 in_scaling=1.,
+                 bias_scale=1.,
+                 activation='tanh'):
+        super(ReservoirLayer, self).__init__()
+        self.w_ih_scale = in_scaling
+        self.b_scale = bias_scale
+        self.density = density
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.alpha = leaking_rate
+        self.spectral_radius = spectral_radius
+        _check_activation(activation)
+        self.activation_name = activation
+
+        self.w_ih = nn.Parameter(torch.empty(hidden_size, input_size), requires_grad=False)
+        self.w_hh = nn.Parameter(torch.empty(hidden_size, hidden_size), requires_grad=False)
+        if bias is not None:      # reservoir.py:47 -- bias=False still creates it
+            self.b_ih = nn.Parameter(torch.empty(hidden_size), requires_grad=False)
+        else:
+            self.register_parameter('b_ih', None)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        """RNG order of reservoir.py:54-75: w_ih, b_ih, w_hh, randperm mask, eigvals."""
+        self.w_ih.data.uniform_(-1, 1)
+        self.w_ih.data.mul_(self.w_ih_scale)
+        if self.b_ih is not None:
+            self.b_ih.data.uniform_(-1, 1)
+            self.b_ih.data.mul_(self.b_scale)
+        self.w_hh.data.uniform_(-1, 1)
+        if self.density < 1:
+            n_units = self.hidden_size * self.hidden_size
+            mask = self.w_hh.data.new_ones(n_units)
+            masked_weights = torch.randperm(n_units)[:int(n_units * (1 - self.density))]
+            mask[masked_weights] = 0.
+            self.w_hh.data.mul_(mask.view(self.hidden_size, self.hidden_size))
+        abs_eigs = torch.linalg.eigvals(self.w_hh.data.cpu()).abs()
+        self.w_hh.data.mul_((self.spectral_radius / torch.max(abs_eigs)).to(self.w_hh.device))
+
+    def _device_weights(self, device):
+        b = self.b_ih if self.b_ih is not None else torch.zeros(self.hidden_size)
+        return tuple(w.detach().to(device=device, dtype=torch.float32).contiguous()
+                     for w in (self.w_ih, self.w_hh, b))
+
+    def run_sequence(self, x, out, h_state=None):
+        """x[T, M, F] -> out[T, M, R] on the device (strided views allowed)."""
+        w_ih, w_hh, b = self._device_weights(x.device)
+        return hip.reservoir_layer(x, w_ih, w_hh, b, self.alpha, self.activation_name,
+                                   out, h_state)
+
+    def forward(self, x, h):
+        """One step (reservoir.py:77-81): a length-1 sequence with initial state h."""
+        dev = x.device
+        xg = x.reshape(1, -1, x.shape[-1]).float()
+        hg = h.reshape(-1, self.hidden_size).float().contiguous().clone()
+        if not xg.is_cuda:
+            hip.require_gpu()
+            xg, hg = xg.cuda(), hg.cuda()
+        out = torch.empty(1, xg.shape[1], self.hidden_size, device=xg.device)
+        self.run_sequence(xg.contiguous(), out, hg)
+        return out[0].reshape(*x.shape[:-1], self.hidden_size).to(dev)
+
+
+class Reservoir(nn.Module):
+    def __init__(self,
+                 input_size,
+                 hidden_size,
+                 input_scaling=1.,
+                 num_layers=1,
+                 leaking_rate=0.9,
+                 spectral_radius=0.9,
+                 density=0.9,
+                 activation='tanh',
+                 bias=True,
+                 alpha_decay=False):
+        super(Reservoir, self).__init__()
+        self.mode = activation
+        self.input_size = input_size
+        self.input_scaling = input_scaling
+        self.hidden_size = hidden_size
+        self.num_layers = num_layers
+        self.leaking_rate = leaking_rate
+        self.spectral_radius = spectral_radius
+        self.density = density
+        self.bias = bias
+        self.alpha_decay = alpha_decay
+
+        layers = []
+        alpha = leaking_rate
+        for i in range(num_layers):
+            layers.append(
+                ReservoirLayer(
+                    input_size=input_size if i == 0 else hidden_size,
+                    hidden_size=hidden_size,
+                    in_scaling=input_scaling,
+                    density=density,
+                    activation=activation,
+                    spectral_radius=spectral_radius,
+                    leaking_rate=alpha))
+            if self.alpha_decay:        # reservoir.py:122-123
+                alpha = np.clip(alpha - 0.1, 0.1, 1.)
+        self.reservoir_layers = nn.ModuleList(layers)
+
+    def reset_parameters(self):
+        for layer in self.reservoir_layers:
+            layer.reset_parameters()
+
+    @property
+    def output_size(self):
+        return len(self.reservoir_layers) * self.hidden_size
+
+    def encode_into(self, x, out, h_state=None):
+        """Device path: x[T, M, F] (CUDA) -> out[T, M, L*R] view, layer-major features
+        (reservoir.py:181-183).  Layer l > 0 consumes layer l-1's slot of ``out`` -- at
+        step s its input is layer l-1's NEW state of step s, as in reservoir.py:174-176.
+        ``h_state``: optional [L, M, R] carried across time chunks."""
+        R = self.hidden_size
+        src = x
+        for i, layer in enumerate(self.reservoir_layers):
+            dst = out[:, :, i * R:(i + 1) * R]
+            layer.run_sequence(src, dst, None if h_state is None else h_state[i])
+            src = dst
+        return out
+
+    def forward(self, x, h0=None, return_last_state=False):
+        # x : b s n f   (reservoir.py:158-186)
+        batch_size, steps, nodes, _ = x.size()
+        dev = x.device
+        xg = x.float()
+        if not xg.is_cuda:
+            hip.require_gpu()
+            xg = xg.cuda()
+        # 'b s n f -> s (b n) f'
+        xs = xg.permute(1, 0, 2, 3).reshape(steps, batch_size * nodes, -1).contiguous()
+        L, R = len(self.reservoir_layers), self.hidden_size
+        state = None
+        if h0 is not None:
+            state = h0.to(xs.device, torch.float32).reshape(L, batch_size * nodes, R).contiguous().clone()
+        out = torch.empty(steps, batch_size * nodes, L * R, device=xs.device)
+        self.encode_into(xs, out, state)
+        # 's (b n) (l f) -> b s n (l f)'
+        out = out.reshape(steps, batch_size, nodes, L * R).permute(1, 0, 2, 3)
+        if return_last_state:
+            return out[:, -1].to(dev)
+        return out.contiguous().to(dev)
+
+    def forward_prealloc(self, x, h0=None, return_last_state=False):
+        """The reference's ``forward_prealloc`` (reservoir.py:131-156) is dead code that
+        reads a not-yet-written slot as the previous state; the name is kept and mapped to
+        the correct recurrence."""
+        if x.dim() == 3:
+            return self.forward(x[None], h0, return_last_state)[0]
+        return self.forward(x, h0, return_last_state)

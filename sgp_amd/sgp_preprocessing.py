@@ -1,0 +1,164 @@
+"""Graph-shift propagation with the reference's call surface
+(``lib/sgp_preprocessing.py``): ``preprocess_adj``, ``sgp_spatial_embedding`` and the
+legacy one-call helpers, computing on the MI355X through ``libsgp_amd.so``."""
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from . import hip
+from .graph import ShiftOperator
+from .nn.reservoir import Reservoir
+
+
+def ensure_list(value):
+    # tsl/utils/python_utils.py:5-10
+    if hasattr(value, '__iter__') and not isinstance(value, str):
+        return list(value)
+    return [value]
+
+
+def _is_sparse_like(obj):
+    return isinstance(obj, ShiftOperator) or (hasattr(obj, 'csr') and hasattr(obj, 'coo')
+                                              and not torch.is_tensor(obj))
+
+
+def _operator_from_sparse(adj, set_diag, remove_diag, gcn_norm) -> ShiftOperator:
+    """A ready sparse object in row = target layout (sgp_preprocessing.py:83-84)."""
+    row, col, val = adj.coo()
+    n = adj.size(0)
+    if val is None:
+        val = torch.ones(row.numel(), dtype=torch.float32)
+    return ShiftOperator.from_coo(row.long().cpu(), col.long().cpu(), val.float().cpu(), n,
+                                  gcn_norm=gcn_norm, set_diag=set_diag, remove_diag=remove_diag)
+
+
+def preprocess_adj(edge_index, edge_weight=None, num_nodes: Optional[int] = None,
+                   gcn_norm: bool = False, set_diag: bool = True,
+                   remove_diag: bool = False) -> ShiftOperator:
+    """lib/sgp_preprocessing.py:67-105.  Returns a :class:`ShiftOperator` (CSR on the
+    host; ``op @ x`` runs on the GPU) in place of a ``torch_sparse.SparseTensor``."""
+    if isinstance(edge_index, (np.ndarray, Tensor)):
+        return ShiftOperator.from_edges(edge_index, edge_weight, num_nodes, gcn_norm=gcn_norm,
+                                        set_diag=set_diag, remove_diag=remove_diag)
+    if _is_sparse_like(edge_index):
+        return _operator_from_sparse(edge_index, set_diag, remove_diag, gcn_norm)
+    raise RuntimeError("Edge index must be (edge_index, edge_weight) tuple "
+                       "or SparseTensor.")
+
+
+def spatial_operators(edge_index, edge_weight, num_nodes, undirected=False,
+                      add_self_loops=False, remove_self_loops=False, bidirectional=False):
+    """Forward (and backward) operators of sgp_spatial_embedding (:182-192, :205-216)."""
+    if undirected:
+        assert bidirectional is False
+    if _is_sparse_like(edge_index):
+        if undirected or bidirectional:
+            raise NotImplementedError("undirected/bidirectional need an edge list")
+        return [_operator_from_sparse(edge_index, add_self_loops, remove_self_loops, False)]
+    if not isinstance(edge_index, (np.ndarray, Tensor)):
+        raise RuntimeError("Edge index must be (edge_index, edge_weight) tuple "
+                           "or SparseTensor.")
+    ops = [ShiftOperator.from_edges(edge_index, edge_weight, num_nodes, gcn_norm=undirected,
+                                    set_diag=add_self_loops, remove_diag=remove_self_loops,
+                                    undirected=undirected)]
+    if bidirectional:
+        ops.append(ShiftOperator.from_edges(edge_index, edge_weight, num_nodes, gcn_norm=False,
+                                            set_diag=add_self_loops,
+                                            remove_diag=remove_self_loops, transpose=True))
+    return ops
+
+
+def propagate_into(out, feat, ops, k):
+    """Fill hop slots of ``out[B, N, (1 + len(ops) * k) * feat]`` in place: slot 0 must
+    already hold x; slot 1 + d*k + (h-1) receives ops[d]^h x.  No concatenation and no
+    temporaries: every hop reads one slot and writes the next."""
+    for d, op in enumerate(ops):
+        src = out[:, :, 0:feat]
+        for h in range(k):
+            s = 1 + d * k + h
+            dst = out[:, :, s * feat:(s + 1) * feat]
+            op.propagate(src, dst)
+            src = dst
+    return out
+
+
+def sgp_spatial_embedding(x,
+                          num_nodes,
+                          edge_index,
+                          edge_weight=None,
+                          k=2,
+                          undirected=False,
+                          add_self_loops=False,
+                          remove_self_loops=False,
+                          bidirectional=False,
+                          one_hot_encoding=False,
+                          dropout_rate=0.):
+    """lib/sgp_preprocessing.py:163-218: ``[x, A x, ..., A^k x (, A_b x, ..., A_b^k x)]``
+    as a list of views into one fused ``[B, N, P * F]`` buffer."""
+    if dropout_rate != 0.:
+        # torch_geometric.utils.dropout_adj with p > 0 draws an edge mask from the RNG
+        # (sgp_preprocessing.py:177-179); no caller in the reference enables it.
+        raise NotImplementedError("dropout_rate > 0 is not supported")
+    ops = spatial_operators(edge_index, edge_weight, num_nodes, undirected=undirected,
+                            add_self_loops=add_self_loops,
+                            remove_self_loops=remove_self_loops,
+                            bidirectional=bidirectional)
+    dev = x.device
+    xg = x.float() if x.dtype != torch.float32 else x
+    squeeze = xg.dim() == 2
+    if squeeze:
+        xg = xg[None]
+    if not xg.is_cuda:
+        hip.require_gpu()
+        xg = xg.cuda()
+    if one_hot_encoding:                              # :194-197
+        ids = torch.eye(num_nodes, dtype=xg.dtype, device=xg.device)
+        xg = torch.cat([xg, ids.unsqueeze(0).expand(xg.size(0), -1, -1)], dim=-1)
+    B, N, F = xg.shape
+    P = 1 + len(ops) * k
+    out = torch.empty(B, N, P * F, dtype=torch.float32, device=xg.device)
+    hip.copy_rows(xg if xg.stride(2) == 1 else xg.contiguous(), out[:, :, :F])
+    propagate_into(out, F, ops, k)
+    if dev != out.device:
+        out = out.to(dev)
+    res = [out[:, :, i * F:(i + 1) * F] for i in range(P)]
+    if squeeze:
+        res = [r[0] for r in res]
+    return res
+
+
+def sgp_spatial_support(edge_index, edge_weight=None, num_nodes=None, k=2, undirected=False,
+                        add_self_loops=False, remove_self_loops=False, bidirectional=False,
+                        global_attr=False):
+    """lib/sgp_preprocessing.py:108-160 (explicit sparse supports for on-the-fly
+    propagation, ``sgp_preprocessing: True``; no shipped config enables it).  SURVEY.md
+    8f row f3 -- not built yet."""
+    raise NotImplementedError("sgp_spatial_support (on-the-fly supports) is a later row "
+                              "of the scope table; use sgp_spatial_embedding")
+
+
+def reservoir_preprocessing_(data, hidden_size: int,
+                             preprocess_exogenous: Union[bool, List] = False,
+                             num_layers=1, leaking_rate=0.9, spectral_radius=0.9,
+                             density=0.9, activation='tanh', bias=True, cuda=False):
+    """lib/sgp_preprocessing.py:40-64 (legacy helper; always computes on the GPU)."""
+    reservoir = Reservoir(input_size=data.size(-1), hidden_size=hidden_size,
+                          num_layers=num_layers, leaking_rate=leaking_rate,
+                          spectral_radius=spectral_radius, density=density,
+                          activation=activation, bias=bias)
+    return reservoir(data[None])[0].to(data.device)
+
+
+def preprocess_dataset(dataset, preprocess_exogenous, reservoir_kwargs, sgp_kwargs):
+    """lib/sgp_preprocessing.py:15-37 (legacy one-call API, uncalled in the reference)."""
+    if isinstance(preprocess_exogenous, bool):
+        preprocess_exogenous = dataset.exogenous.keys() if preprocess_exogenous else []
+    preprocess_exogenous = ensure_list(preprocess_exogenous)
+    data, _ = dataset.get_tensors(['data'] + preprocess_exogenous, preprocess=True, cat_dim=-1)
+    res = reservoir_preprocessing_(data, **reservoir_kwargs)
+    res = sgp_spatial_embedding(res, num_nodes=data.size(1), edge_index=dataset.edge_index,
+                                edge_weight=dataset.edge_weight, **sgp_kwargs)
+    dataset.add_exogenous('processed_x', torch.cat(res, -1), add_to_input_map=False)
+    dataset.set_input_map({'x': ['processed_x']})

@@ -1,0 +1,266 @@
+"""Host-side logic of the product (graph operators, tile plans, weight init, API surface,
+harness) against the oracle and the golden vectors.  CPU-only."""
+import argparse
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import sgp_amd
+from conftest import GOLDEN, golden_files
+from oracle import sgp_oracle as O
+from sgp_amd import graph, synthetic
+from sgp_amd.sgp_preprocessing import spatial_operators
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+FLAGS = [dict(), dict(bidirectional=True), dict(add_self_loops=True),
+         dict(remove_self_loops=True), dict(undirected=True),
+         dict(undirected=True, add_self_loops=True),
+         dict(bidirectional=True, remove_self_loops=True)]
+
+
+@pytest.mark.parametrize("flags", FLAGS)
+def test_shift_operators_match_oracle(flags):
+    z = load("g1_spatial_plain_k1.npz")
+    n = z["x"].shape[1]
+    for ew in (torch.from_numpy(z["edge_weight"]), None):
+        ops = spatial_operators(torch.from_numpy(z["edge_index"]), ew, n, **flags)
+        ref = O.shift_operators_dense(z["edge_index"], None if ew is None else ew, n, **flags)
+        assert len(ops) == len(ref)
+        for a, b in zip(ops, ref):
+            assert torch.allclose(a.to_dense().double(), b, rtol=1e-6, atol=1e-7)
+            rp = a.rowptr.long()
+            assert rp[0] == 0 and rp[-1] == a.nnz() and bool((rp[1:] >= rp[:-1]).all())
+
+
+def test_preprocess_adj_variants():
+    z = load("g1_spatial_plain_k1.npz")
+    n = z["x"].shape[1]
+    ei = torch.from_numpy(z["edge_index"])
+    ew = torch.from_numpy(z["edge_weight"])
+    a = sgp_amd.preprocess_adj(ei, ew, num_nodes=n)                 # set_diag default True
+    ref = O.normalize_dense(O.dense_adjacency(ei, ew, n), set_diag=True)
+    assert torch.allclose(a.to_dense().double(), ref, atol=1e-7)
+    b = sgp_amd.preprocess_adj(z["edge_index"], z["edge_weight"], num_nodes=n, set_diag=False)
+    ref = O.normalize_dense(O.dense_adjacency(ei, ew, n))
+    assert torch.allclose(b.to_dense().double(), ref, atol=1e-7)
+    # a ready sparse object (row = target layout) is accepted, like SparseTensor at :83-84
+    c = sgp_amd.preprocess_adj(b, set_diag=False)
+    ref2 = O.normalize_dense(ref)
+    assert torch.allclose(c.to_dense().double(), ref2, atol=1e-6)
+    with pytest.raises(RuntimeError):
+        sgp_amd.preprocess_adj([[0, 1], [1, 0]])
+    with pytest.raises(AssertionError):
+        spatial_operators(ei, ew, n, undirected=True, bidirectional=True)
+
+
+def test_zero_degree_rows_and_isolated_nodes():
+    ei = torch.tensor([[0, 1, 1], [1, 0, 0]])
+    op = graph.ShiftOperator.from_edges(ei, torch.tensor([1., 2., 3.]), 4)
+    d = op.to_dense()
+    assert torch.allclose(d[0], torch.tensor([0., 1., 0., 0.]))
+    assert float(d[2:].abs().sum()) == 0.0
+    op = graph.ShiftOperator.from_edges(torch.zeros(2, 0, dtype=torch.long), None, 3)
+    assert op.nnz() == 0 and op.rowptr.tolist() == [0, 0, 0, 0]
+
+
+def _check_plan(op, plan):
+    rowptr = op.rowptr.numpy().astype(np.int64)
+    col, val = op.col.numpy(), op.val.numpy()
+    trow, uptr, ucol = plan.trow.numpy(), plan.uptr.numpy(), plan.ucol.numpy()
+    erow = plan.erow.numpy()
+    ecol = plan.ecol.numpy().view(np.uint16)
+    assert trow[0] == 0 and trow[-1] == op.num_nodes and (np.diff(trow) > 0).all()
+    assert np.diff(trow).max() == plan.tile_rows and len(trow) == plan.n_tiles + 1
+    assert np.diff(uptr).max() == plan.max_union
+    assert (np.diff(erow) % 16 == 0).all() and np.diff(erow).max() == plan.max_row_edges
+    for k in range(plan.n_tiles):
+        u = ucol[uptr[k]:uptr[k + 1]]
+        assert (np.diff(u) > 0).all()                              # sorted, distinct
+        for r in range(trow[k], trow[k + 1]):
+            d = rowptr[r + 1] - rowptr[r]
+            e0 = erow[r]
+            assert (u[ecol[e0:e0 + d]] == col[rowptr[r]:rowptr[r + 1]]).all()
+            assert (plan.eval.numpy()[e0:e0 + d] == val[rowptr[r]:rowptr[r + 1]]).all()
+            assert (plan.eval.numpy()[e0 + d:erow[r + 1]] == 0).all()
+            assert (ecol[e0 + d:erow[r + 1]] == 0).all()
+
+
+LIMITS = dict(max_union=512, max_tile_rows=128, max_row_edges=128)
+
+
+def test_tile_plan_knn_graph():
+    ei, ew, _ = synthetic.knn_graph(3000, 40, seed=5)
+    op = graph.ShiftOperator.from_edges(ei, ew, 3000)
+    plan = graph.build_tile_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), 3000, **LIMITS)
+    assert plan is not None and plan.tile_rows == 64 and plan.max_row_edges == 48
+    _check_plan(op, plan)
+
+
+def test_tile_plan_splits_oversized_tiles_and_gives_up_on_random_graphs():
+    ei, ew, _ = synthetic.knn_graph(3000, 40, seed=5)
+    op = graph.ShiftOperator.from_edges(ei, ew, 3000)
+    small = graph.build_tile_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), 3000,
+                                  max_union=160, max_tile_rows=128, max_row_edges=128)
+    assert small is not None and small.max_union <= 160
+    assert np.diff(small.trow.numpy()).min() < small.tile_rows      # some tiles were halved
+    _check_plan(op, small)
+    ei, ew = synthetic.random_graph(4000, 100, seed=5)
+    op = graph.ShiftOperator.from_edges(ei, ew, 4000)
+    assert graph.build_tile_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), 4000,
+                                 **LIMITS) is None
+    # rows longer than the kernel's register budget -> generic kernel
+    ei, ew = synthetic.random_graph(300, 200, seed=1)
+    op = graph.ShiftOperator.from_edges(ei, ew, 300)
+    assert graph.build_tile_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), 300,
+                                 **LIMITS) is None
+
+
+def test_tile_plan_small_sparse_graph():
+    ei, ew = synthetic.sparse_traffic_graph(207, 1515, seed=3)
+    op = graph.ShiftOperator.from_edges(ei, ew, 207)
+    plan = graph.build_tile_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), 207, **LIMITS)
+    assert plan is not None
+    _check_plan(op, plan)
+
+
+# ------------------------------------------------------------------ weights / API surface
+@pytest.mark.parametrize("name", [f for f in golden_files("g4_seed") if "gesn" not in f])
+def test_seed_reproduces_reference_weights(name):
+    z = load(name)
+    f, r, L, a, rho, dens, scale = z["cfg"]
+    torch.manual_seed(int(z["seed"]))
+    res = sgp_amd.Reservoir(input_size=int(f), hidden_size=int(r), num_layers=int(L),
+                            leaking_rate=a, spectral_radius=rho, density=dens,
+                            input_scaling=scale, alpha_decay=True)
+    after = torch.rand(4)
+    ref = O.layers_from_npz(z)
+    for layer, g in zip(res.reservoir_layers, ref):
+        assert torch.equal(layer.w_ih.data, g["w_ih"])
+        assert torch.equal(layer.w_hh.data, g["w_hh"])
+        assert torch.equal(layer.b_ih.data, g["b_ih"])
+        assert float(layer.alpha) == g["alpha"]
+    assert torch.equal(after, torch.from_numpy(z["rng_after"]))
+
+
+def test_constructor_signatures_match_reference():
+    # names are API: filter_args routes CLI/YAML values by __init__ parameter name
+    # (tsl/utils/parser_utils.py:69-81); lists from lib/nn/encoders/*.py and reservoir.py:85-95
+    def params(cls):
+        return list(inspect.signature(cls.__init__).parameters)[1:]
+    assert params(sgp_amd.SGPEncoder) == [
+        "input_size", "reservoir_size", "reservoir_layers", "leaking_rate", "spectral_radius",
+        "density", "input_scaling", "receptive_field", "bidirectional", "alpha_decay",
+        "global_attr", "add_self_loops", "undirected", "reservoir_activation"]
+    assert params(sgp_amd.SGPTemporalEncoder) == [
+        "input_size", "reservoir_size", "reservoir_layers", "leaking_rate", "spectral_radius",
+        "density", "input_scaling", "alpha_decay", "reservoir_activation"]
+    assert params(sgp_amd.SGPSpatialEncoder) == [
+        "receptive_field", "bidirectional", "undirected", "global_attr", "add_self_loops"]
+    assert params(sgp_amd.Reservoir) == [
+        "input_size", "hidden_size", "input_scaling", "num_layers", "leaking_rate",
+        "spectral_radius", "density", "activation", "bias", "alpha_decay"]
+    d = inspect.signature(sgp_amd.SGPTemporalEncoder.__init__).parameters
+    assert (d["reservoir_size"].default, d["density"].default, d["leaking_rate"].default) == (32, 0.7, 0.9)
+    d = inspect.signature(sgp_amd.Reservoir.__init__).parameters
+    assert d["density"].default == 0.9 and d["bias"].default is True
+    d = inspect.signature(sgp_amd.sgp_spatial_embedding).parameters
+    assert list(d) == ["x", "num_nodes", "edge_index", "edge_weight", "k", "undirected",
+                       "add_self_loops", "remove_self_loops", "bidirectional",
+                       "one_hot_encoding", "dropout_rate"]
+
+
+def test_cli_flags_on_plain_argparse():
+    p = sgp_amd.SGPEncoder.add_model_specific_args(argparse.ArgumentParser())
+    a = p.parse_args([])
+    assert (a.reservoir_size, a.reservoir_layers, a.receptive_field) == (32, 1, 1)
+    assert (a.spectral_radius, a.leaking_rate, a.density, a.input_scaling) == (0.9, 0.9, 0.7, 1.)
+    assert (a.bidirectional, a.undirected, a.add_self_loops, a.alpha_decay, a.global_attr) == \
+        (False,) * 5
+    assert a.reservoir_activation == "tanh"
+    a = p.parse_args(["--bidirectional", "--global-attr", "true", "--reservoir-size", "64"])
+    assert a.bidirectional is True and a.global_attr is True and a.reservoir_size == 64
+
+    class TT(argparse.ArgumentParser):                 # test_tube-like parser
+        def opt_list(self, *args, options=None, tunable=False, **kw):
+            self.add_argument(*args, **kw)
+    a = sgp_amd.SGPTemporalEncoder.add_model_specific_args(TT()).parse_args([])
+    assert a.receptive_field == 1 and a.reservoir_size == 32
+
+
+def test_activation_errors_match_reference():
+    with pytest.raises(AssertionError):
+        sgp_amd.Reservoir(3, 8, activation="gelu")
+    with pytest.raises(ValueError):                    # tsl/nn/utils/utils.py:44
+        sgp_amd.Reservoir(3, 8, activation="identity")
+    layer = sgp_amd.ReservoirLayer(3, 8, 0.9, 0.9, bias=False)
+    assert layer.b_ih is not None                      # reservoir.py:47 quirk
+    assert sgp_amd.ReservoirLayer(3, 8, 0.9, 0.9, bias=None).b_ih is None
+
+
+def test_alpha_decay_schedule():
+    res = sgp_amd.Reservoir(3, 8, num_layers=8, leaking_rate=1.0, alpha_decay=True)
+    got = [float(l.alpha) for l in res.reservoir_layers]
+    assert got == O.alpha_schedule(1.0, 8, True)
+    assert np.allclose(got, [1., .9, .8, .7, .6, .5, .4, .3])
+
+
+class FakeDataset:
+    def __init__(self, data, u, ei, ew):
+        self._t = {"data": data, "u": u}
+        self.exogenous = {"u": u}
+        self.edge_index, self.edge_weight = ei, ew
+        self.calls = []
+
+    def get_tensors(self, keys, preprocess=False, cat_dim=None):
+        self.calls.append(("get_tensors", list(keys), preprocess, cat_dim))
+        ts = [self._t[k] if self._t[k].dim() == 3 else
+              self._t[k][:, None].expand(-1, self._t["data"].shape[1], -1) for k in keys]
+        return torch.cat(ts, cat_dim), None
+
+    def add_exogenous(self, name, value, add_to_input_map=True):
+        self.calls.append(("add_exogenous", name, add_to_input_map))
+        self._t[name] = value
+
+    def set_input_map(self, m):
+        self.calls.append(("set_input_map", m))
+        self.input_map = m
+
+
+class StubEncoder:
+    """Host-logic stand-in so the harness can be exercised without a GPU."""
+
+    def __init__(self, input_size, **kw):
+        self.input_size = input_size
+
+    def __call__(self, x, edge_index, edge_weight):
+        assert x.shape[-1] == self.input_size
+        return x.sum(-1, keepdim=True)
+
+
+@pytest.mark.parametrize("name", golden_files("g5_"))
+def test_encode_dataset_harness_logic(name, tmp_path):
+    z = load(name)
+    ds = FakeDataset(torch.from_numpy(z["data"]), torch.from_numpy(z["u"]),
+                     torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_weight"]))
+    enc_exo, keep_raw = bool(z["encode_exogenous"]), bool(z["keep_raw"])
+    path = tmp_path / "enc.pt"
+    out = sgp_amd.encode_dataset(ds, StubEncoder, dict(input_size=3 if enc_exo else 1),
+                                 encode_exogenous=enc_exo, keep_raw=keep_raw, save_path=str(path))
+    assert out is ds and len(ds.calls) == int(z["n_calls"])
+    assert ds.calls[0] == ("get_tensors", list(z["get_tensors_keys"]), True, -1)
+    assert ds.calls[1] == ("add_exogenous", "encoded_x", False)
+    assert ds.input_map["x"] == list(z["input_map_x"])
+    assert ds.input_map.get("u", []) == list(z["input_map_u"])
+    assert torch.equal(torch.load(path), ds._t["encoded_x"])
+
+
+def test_spatial_support_is_declared_out_of_scope():
+    with pytest.raises(NotImplementedError):
+        sgp_amd.sgp_spatial_support(torch.zeros(2, 0, dtype=torch.long))

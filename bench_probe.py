@@ -16,6 +16,7 @@ def timeit(fn, n=3):
 
 
 def main():
+    only_spmm = len(sys.argv) > 1 and sys.argv[1] == "spmm"
     N, T, D, K = 100000, 256, 64, 4
     ei, ew, _ = synthetic.knn_graph(N, 100)
     op = graph.ShiftOperator.from_edges(ei, ew, N)
@@ -25,6 +26,8 @@ def main():
     for force in ("tiled", "csr"):
         ms = timeit(lambda: op.propagate(x, y, force=force))
         print(f"spmm {force}: {ms:.2f} ms  {bytes_hop / ms / 1e6:.1f} GB/s  frac {bytes_hop / ms / 1e6 / 8000:.3f}", flush=True)
+    if only_spmm:
+        return
     eir, ewr = synthetic.random_graph(N, 100)
     opr = graph.ShiftOperator.from_edges(eir, ewr, N)
     ms = timeit(lambda: opr.propagate(x, y))

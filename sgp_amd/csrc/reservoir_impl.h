@@ -56,8 +56,12 @@ struct ResArgs {
     int tiles_per_wave, n_tiles;
 };
 
+// waves per SIMD the register budget is sized for (more co-resident waves = the MFMA pipe
+// stays busy while another wave runs its activation / loads / stores)
+constexpr int min_waves(int JT, int NT) { return JT <= 4 ? 4 : (JT <= 8 ? 2 : 1); }
+
 template <int JT, int NKX, int NT, bool WLDS>
-__global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
+__global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float* wsrc = a.wp;
     if constexpr (WLDS) {
@@ -73,9 +77,12 @@ __global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int n_in = lane & 15, q = lane >> 4;
+    // tiles are dealt to waves as evenly as possible: wave w owns [w*n/W, (w+1)*n/W), 0..NT tiles
     const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int tile0 = wave * NT;
-    if (tile0 >= a.n_tiles) return;
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    const int tile0 = (int)((long long)wave * a.n_tiles / n_waves);
+    const int tile1 = (int)((long long)(wave + 1) * a.n_tiles / n_waves);
+    if (tile0 >= tile1) return;
 
     int node[NT];
     bool ok[NT];
@@ -83,7 +90,7 @@ __global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         node[i] = (tile0 + i) * 16 + n_in;
-        ok[i] = (tile0 + i) < a.n_tiles && node[i] < a.N;
+        ok[i] = (tile0 + i) < tile1 && node[i] < a.N;
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             h[i][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -101,40 +108,46 @@ __global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
                        ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
 
     for (int t = 0; t < a.T; ++t) {
-        // input operands of this step for all my tiles (issued first; consumed after the
-        // recurrent part so their latency hides under its MFMAs)
-        float xr[NT][NKX];
+        // Keep the weight fragments in LDS/L2: without this the compiler hoists all of them
+        // out of the time loop into ~128 VGPRs and occupancy drops to one wave per SIMD.
+        int wo = 0;
+        asm volatile("" : "+v"(wo));
+        const float* bias_t = bias + wo;
+        const float* wx_t = wx + wo;
+        const float* wh_t = wh + wo;
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
-            if (x_vec) {
+            if (tile0 + i >= tile1) continue;          // wave-uniform
+            // input operands of this tile: issued first, consumed after the recurrent part so
+            // their latency hides under its MFMAs (and under the other waves of the SIMD)
+            float xr[NKX];
+            {
+                const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
+                if (x_vec) {
 #pragma unroll
-                for (int k4 = 0; k4 < NKX / 4; ++k4) {
-                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (ok[i] && q * NKX + 4 * k4 < a.F) v = *reinterpret_cast<const f32x4*>(xp + 4 * k4);
-                    xr[i][4 * k4 + 0] = v.x; xr[i][4 * k4 + 1] = v.y;
-                    xr[i][4 * k4 + 2] = v.z; xr[i][4 * k4 + 3] = v.w;
+                    for (int k4 = 0; k4 < NKX / 4; ++k4) {
+                        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (ok[i] && q * NKX + 4 * k4 < a.F) v = *reinterpret_cast<const f32x4*>(xp + 4 * k4);
+                        xr[4 * k4 + 0] = v.x; xr[4 * k4 + 1] = v.y;
+                        xr[4 * k4 + 2] = v.z; xr[4 * k4 + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < NKX; ++ks)
+                        xr[ks] = (ok[i] && q * NKX + ks < a.F) ? xp[ks] : 0.f;
                 }
-            } else {
-#pragma unroll
-                for (int ks = 0; ks < NKX; ++ks)
-                    xr[i][ks] = (ok[i] && q * NKX + ks < a.F) ? xp[ks] : 0.f;
             }
-        }
-
-#pragma unroll
-        for (int i = 0; i < NT; ++i) {
             f32x4 acc[JT];
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt)
-                acc[jt] = *reinterpret_cast<const f32x4*>(bias + jt * 16 + q * 4);
+                acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
             // recurrent part: k-step (kb, s) <-> register s of state tile kb
 #pragma unroll
             for (int kb = 0; kb < JT; ++kb) {
                 f32x4 wf[JT];
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
-                    wf[jt] = *reinterpret_cast<const f32x4*>(wh + ((jt * JT + kb) * 64 + lane) * 4);
+                    wf[jt] = *reinterpret_cast<const f32x4*>(wh_t + ((jt * JT + kb) * 64 + lane) * 4);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256) void reservoir_layer(ResArgs a) {
             for (int ks = 0; ks < NKX; ++ks) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
-                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx[(jt * NKX + ks) * 64 + lane], xr[i][ks],
+                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane], xr[ks],
                                                                    acc[jt], 0, 0, 0);
             }
             // activation
@@ -215,12 +228,16 @@ template <int JT, int NKX, int NT>
 int launch_layer(ResArgs a, hipStream_t s) {
     const long long wbytes = packed_floats(JT, NKX) * 4;
     a.n_tiles = (a.N + 15) / 16;
-    const int n_waves = (a.n_tiles + NT - 1) / NT;
-    // small problems: one wave per workgroup so every wave gets a CU of its own
-    int wpw = (n_waves + 255) / 256;
-    if (wpw < 1) wpw = 1;
-    if (wpw > 4) wpw = 4;
-    const int grid = (n_waves + wpw - 1) / wpw;
+    // Small problems: one single-tile wave per workgroup (every wave gets its own CU).
+    // Large problems: a wave count that is a multiple of 1024 SIMDs, tiles dealt evenly,
+    // so every SIMD carries the same number of waves and (almost) of tiles.
+    int wpw = 1, grid = a.n_tiles;
+    if (a.n_tiles > 1024) {
+        const int rounds = (a.n_tiles + 1024 * NT - 1) / (1024 * NT);
+        const int n_waves = 1024 * rounds;
+        wpw = 4;
+        grid = n_waves / wpw;
+    }
     if constexpr (packed_floats(JT, NKX) * 4 <= kLdsLimit) {
         auto kern = reservoir_layer<JT, NKX, NT, true>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -235,10 +252,9 @@ int launch_layer(ResArgs a, hipStream_t s) {
 
 template <int JT, int NKX>
 int launch_nt(const ResArgs& a, hipStream_t s) {
-    // two tiles per wave once every SIMD already has >= 2 waves of single tiles
     const int n_tiles = (a.N + 15) / 16;
-    if constexpr (JT * 4 * 2 + NKX * 2 <= 160) {
-        if (n_tiles >= 2048) return launch_layer<JT, NKX, 2>(a, s);
+    if constexpr (JT <= 4) {
+        if (n_tiles > 4096) return launch_layer<JT, NKX, 2>(a, s);
     }
     return launch_layer<JT, NKX, 1>(a, s);
 }

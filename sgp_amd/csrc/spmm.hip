@@ -14,6 +14,7 @@
 //                   per 16 edges and handed round the row with row_ror, so the only LDS
 //                   traffic in the inner loop is one ds_read_b128 per (edge, 4 features).
 #include "common.h"
+#include <stdlib.h>
 
 using sgp::f32x4;
 
@@ -129,6 +130,42 @@ __device__ __forceinline__ void edge_half(const char* lds, int off, float w, int
     for (int i = 0; i < 8; ++i) acc += wv[i] * xv[i];
 }
 
+// Same 8 rotations with the weight rotation folded into the FMA: v_fmac_f32_dpp takes its
+// src0 (the edge weight) through row_ror, so a step is add_dpp + ds_read_b128 + 4 fmac_dpp.
+#define SGP_FMAC_ROR(S, ACC, W, X)                                                              \
+    asm("v_fmac_f32_dpp %0, %1, %2 row_ror:" #S " row_mask:0xf bank_mask:0xf" : "+v"(ACC) : "v"(W), "v"(X))
+#define SGP_STEP_ROR(S, I)                                                                      \
+    SGP_FMAC_ROR(S, acc.x, w, xv[I].x); SGP_FMAC_ROR(S, acc.y, w, xv[I].y);                     \
+    SGP_FMAC_ROR(S, acc.z, w, xv[I].z); SGP_FMAC_ROR(S, acc.w, w, xv[I].w);
+template <int S0, int ABL = 0>
+__device__ __forceinline__ void edge_half_dpp(const char* lds, int off, float w, int li16, f32x4& acc) {
+    int ad[8];
+    f32x4 xv[8];
+#define SGP_ROT(i) ad[i] = ror_i<S0 + i>(off) + li16;
+    SGP_ROT(0) SGP_ROT(1) SGP_ROT(2) SGP_ROT(3) SGP_ROT(4) SGP_ROT(5) SGP_ROT(6) SGP_ROT(7)
+#undef SGP_ROT
+    if constexpr (ABL == 3) {          // ablation: no LDS reads (operands faked from the address)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { float f = __int_as_float(ad[i]); xv[i] = f32x4{f, f, f, f}; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xv[i] = *reinterpret_cast<const f32x4*>(lds + ad[i]);
+    }
+    if constexpr (ABL == 2) {          // ablation: no FMAs (reads kept alive)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(xv[i].x), "v"(xv[i].y), "v"(xv[i].z), "v"(xv[i].w));
+        return;
+    }
+    if constexpr (S0 == 0) {
+        acc += w * xv[0];
+        SGP_STEP_ROR(1, 1) SGP_STEP_ROR(2, 2) SGP_STEP_ROR(3, 3) SGP_STEP_ROR(4, 4)
+        SGP_STEP_ROR(5, 5) SGP_STEP_ROR(6, 6) SGP_STEP_ROR(7, 7)
+    } else {
+        SGP_STEP_ROR(8, 0) SGP_STEP_ROR(9, 1) SGP_STEP_ROR(10, 2) SGP_STEP_ROR(11, 3)
+        SGP_STEP_ROR(12, 4) SGP_STEP_ROR(13, 5) SGP_STEP_ROR(14, 6) SGP_STEP_ROR(15, 7)
+    }
+}
+
 struct TiledArgs {
     const int* trow; const int* uptr; const int* ucol; const int* erow; const unsigned short* ecol; const float* eval;
     int tile_rows, n_tiles;
@@ -142,7 +179,7 @@ struct TiledArgs {
 // groups (DPP rows).  PASSES: staged rows per thread (register prefetch depth), capacity
 // U_MAX = PASSES * NTHR / 16 rows.  Each edge group owns RPG rows of the tile and keeps their
 // edge records (NB batches of 16 per row) in registers for the whole time chunk.
-template <int NTHR, int PASSES, int RPG, int NB, bool HALO>
+template <int NTHR, int PASSES, int RPG, int NB, bool HALO, int VARIANT>
 __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int FT = 64;
@@ -206,8 +243,11 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
         }
     }
 
+    constexpr bool kStage = VARIANT != 4 && VARIANT != 5;
+    constexpr bool kBarrier = VARIANT != 5;
     f32x4 stage[PASSES];
     auto issue = [&](int t) {
+        if constexpr (!kStage) return;
         const float* xt = a.src.x + (long long)t * a.src.xbs + f_base + li * 4;
         const float* ht = a.src.xh + (long long)t * a.src.xhbs + f_base + li * 4;
 #pragma unroll
@@ -221,11 +261,13 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     issue(t_begin);
 
     for (int t = t_begin; t < t_end; ++t) {
+        if constexpr (kStage) {
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            if (p < n_pass)
-                *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
-        __syncthreads();
+            for (int p = 0; p < PASSES; ++p)
+                if (p < n_pass)
+                    *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
+        }
+        if constexpr (kBarrier) __syncthreads();
         if (t + 1 < t_end) issue(t + 1);          // in flight under the compute below
 
 #pragma unroll
@@ -235,26 +277,38 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 if (n < nbat[g]) {
-                    edge_half<0>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
-                    edge_half<8>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                    if constexpr (VARIANT >= 1) {
+                        constexpr int ABL = (VARIANT == 2 || VARIANT == 3) ? VARIANT : 0;
+                        edge_half_dpp<0, ABL>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                        edge_half_dpp<8, ABL>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                    } else {
+                        edge_half<0>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                        edge_half<8>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                    }
                 }
             }
             if (rr < rows_here)
                 st4(a.Y + (long long)t * a.ybs + (long long)(row0 + rr) * a.yrs + f_base + li * 4, acc);
         }
-        __syncthreads();                          // all reads done before the next overwrite
+        if constexpr (kBarrier) __syncthreads();   // all reads done before the next overwrite
     }
 }
 
-constexpr int kTiledThreads = 512;
-constexpr int kTiledPasses = 16;
+constexpr int kTiledThreads = 1024;
+constexpr int kTiledPasses = 8;
 constexpr int kTiledCapacity = kTiledPasses * kTiledThreads / 16;   // staged rows per tile
 constexpr int kTiledGroups = kTiledThreads / 16;                    // rows in flight per workgroup
 
-template <int RPG, int NB, bool HALO>
-int launch_tiled(const TiledArgs& a, hipStream_t s) {
+int tiled_variant() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGP_SPMM_VARIANT"); v = e ? atoi(e) : 1; }
+    return v;
+}
+
+template <int RPG, int NB, bool HALO, int VARIANT>
+int launch_tiled_v(const TiledArgs& a, hipStream_t s) {
     const size_t lds_bytes = (size_t)kTiledCapacity * 64 * 4;
-    auto kern = spmm_tiled<kTiledThreads, kTiledPasses, RPG, NB, HALO>;
+    auto kern = spmm_tiled<kTiledThreads, kTiledPasses, RPG, NB, HALO, VARIANT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "spmm_tiled: LDS opt-in: %s", hipGetErrorString(e));
@@ -263,10 +317,24 @@ int launch_tiled(const TiledArgs& a, hipStream_t s) {
     return sgp::check_launch("spmm_tiled");
 }
 
+template <int RPG, int NB, bool HALO>
+int launch_tiled(const TiledArgs& a, hipStream_t s) {
+    switch (tiled_variant()) {
+        case 0: return launch_tiled_v<RPG, NB, HALO, 0>(a, s);
+#ifdef SGP_ABLATION
+        case 2: return launch_tiled_v<RPG, NB, HALO, 2>(a, s);
+        case 3: return launch_tiled_v<RPG, NB, HALO, 3>(a, s);
+        case 4: return launch_tiled_v<RPG, NB, HALO, 4>(a, s);
+        case 5: return launch_tiled_v<RPG, NB, HALO, 5>(a, s);
+#endif
+        default: return launch_tiled_v<RPG, NB, HALO, 1>(a, s);
+    }
+}
+
 template <bool HALO>
 int dispatch_tiled(const TiledArgs& a, int rpg, int nb, hipStream_t s) {
 #define SGP_T(R, B) if (rpg == R && nb == B) return launch_tiled<R, B, HALO>(a, s);
-    SGP_T(1, 2) SGP_T(2, 2) SGP_T(4, 2) SGP_T(1, 8) SGP_T(2, 8) SGP_T(4, 8)
+    SGP_T(1, 2) SGP_T(2, 2) SGP_T(1, 8)
 #undef SGP_T
     return sgp::fail(SGP_EUNSUP, "spmm_tiled: no kernel for rows/group=%d batches=%d", rpg, nb);
 }
@@ -278,7 +346,7 @@ extern "C" {
 int32_t sgp_spmm_tiled_max_union(int32_t feat) {
     return (feat > 0 && feat % 64 == 0) ? kTiledCapacity : 0;
 }
-int32_t sgp_spmm_tiled_max_tile_rows(void) { return 4 * kTiledGroups; }
+int32_t sgp_spmm_tiled_max_tile_rows(void) { return 2 * kTiledGroups; }
 int32_t sgp_spmm_tiled_max_row_edges(void) { return 8 * 16; }
 
 int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
@@ -361,8 +429,7 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
-    const int rpg_need = (tile_rows + kTiledGroups - 1) / kTiledGroups;
-    const int rpg = rpg_need <= 1 ? 1 : (rpg_need <= 2 ? 2 : 4);
+    const int rpg = (tile_rows + kTiledGroups - 1) / kTiledGroups;
     const int nb = max_row_edges <= 32 ? 2 : 8;
     hipStream_t s = (hipStream_t)stream;
     return Xh ? dispatch_tiled<true>(a, rpg, nb, s) : dispatch_tiled<false>(a, rpg, nb, s);

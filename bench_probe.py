@@ -23,7 +23,8 @@ def main():
     x = torch.randn(T, N, D, device="cuda")
     y = torch.empty_like(x)
     bytes_hop = 2 * N * T * D * 4 + op.nnz() * 8 + (N + 1) * 4
-    for force in ("tiled", "csr"):
+    print("group fill", op.tile_plan(D, torch.device("cuda")).group_fill, flush=True)
+    for force in ("mfma", "tiled", "csr"):
         ms = timeit(lambda: op.propagate(x, y, force=force))
         print(f"spmm {force}: {ms:.2f} ms  {bytes_hop / ms / 1e6:.1f} GB/s  frac {bytes_hop / ms / 1e6 / 8000:.3f}", flush=True)
     if only_spmm:

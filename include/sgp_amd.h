@@ -98,6 +98,30 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                        sgp_stream_t stream);
+/* Matrix-core row-group kernel.  Tiles and their distinct-column lists (tile_row_ptr / uptr /
+ * ucol) are as above with tiles of at most 64 rows.  Every tile is cut into 16 groups of 4
+ * consecutive rows (group g of tile k = rows tile_row_ptr[k] + 4g ..); a group walks the sorted
+ * union of its rows' columns in "steps", 4 steps per chunk, tail steps padded with offset 0 /
+ * weight 0; gptr[k * 16 + g] .. gptr[k * 16 + g + 1] is the group's chunk range.  The 4-row x
+ * 64-feature outer product of every step is one v_mfma_f32_4x4x1_16b_f32 (exact fp32):
+ *   goff[chunk][4]          LDS byte offset (index in the tile's ucol list * 256) of each step
+ *                           (read through the scalar cache)
+ *   gw[chunk][row][step]    weights, 0 where the row has no such column (copied to LDS once
+ *                           per workgroup)
+ * Limits: sgp_spmm_mfma_max_union() staged rows per tile, sgp_spmm_mfma_max_chunks() chunks
+ * per tile. */
+int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
+                      const int32_t* gptr, const int32_t* goff, const float* gw,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_chunks,
+                      const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                      const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                      int32_t n_own,
+                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                      sgp_stream_t stream);
+int32_t sgp_spmm_mfma_max_union(void);
+int32_t sgp_spmm_mfma_max_chunks(void);
+
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and
  * largest padded per-row edge count. */

@@ -294,6 +294,158 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- MFMA row-group kernel
+// Same tile staging as spmm_tiled, different inner product: a wave owns FOUR consecutive output
+// rows ("row group") and walks the sorted union of their columns.  v_mfma_f32_4x4x1_16b_f32
+// performs 16 independent 4x1 (x) 1x4 outer products per instruction -- exactly "4 output rows
+// (A = their weights for one source column) times 64 features (B = the staged source row, one
+// float per lane)".  The
+// accumulator (4 VGPRs) holds rows 0..3 of the group for feature = lane.  Exact fp32 FMAs, so
+// numerics equal the VALU kernels.  Per step the VALU only forms one LDS address; weights come
+// from an LDS-resident copy of the group's stream (one ds_read_b128 per 4 steps, lane (b, i)
+// reads row i's weights), offsets arrive as SGPRs through the scalar cache.
+//   goff  [n_chunks][4]      int32  byte offset of the staged row of each step
+//   gw    [n_chunks][4][4]   float  w[row i][step] of the chunk
+struct MfmaArgs {
+    const int* trow; const int* uptr; const int* ucol;
+    const int* gptr; const int* goff; const float* gw;
+    int n_tiles;
+    Src src;
+    float* Y; long long yrs, ybs;
+    int n_rows, batch, feat;
+    int t_chunk, n_tchunks;
+};
+
+constexpr int kMfmaPasses = 7;                       // 448 staged rows
+constexpr int kMfmaStageBytes = kMfmaPasses * 64 * 256;
+constexpr int kMfmaMaxChunks = (160 * 1024 - kMfmaStageBytes) / 64;   // LDS-resident weight chunks per tile
+
+template <bool HALO>
+__global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int PASSES = kMfmaPasses;
+    constexpr int FT = 64;
+    constexpr int RPP = 64;
+    char* wlds = lds + kMfmaStageBytes;
+
+    const int nwg = a.n_tiles * a.n_tchunks;
+    const int orig = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int tile = w % a.n_tiles;
+    const int tchunk = w / a.n_tiles;
+    const int f_base = blockIdx.y * FT;
+
+    const int tid = threadIdx.x;
+    const int li = tid & 15;
+    const int eg = tid >> 4;
+    const int u0 = a.uptr[tile];
+    const int nU = a.uptr[tile + 1] - u0;
+
+    int soff[PASSES];
+    unsigned halo_mask = 0;
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int u = p * RPP + eg;
+        const int c = (u < nU) ? a.ucol[u0 + u] : 0;
+        if (HALO && c >= a.src.n_own) {
+            halo_mask |= 1u << p;
+            soff[p] = (c - a.src.n_own) * (int)a.src.xhrs;
+        } else {
+            soff[p] = c * (int)a.src.xrs;
+        }
+    }
+    const int n_pass = (nU + RPP - 1) / RPP;
+
+    const int t_begin = tchunk * a.t_chunk;
+    const int t_end = min(a.batch, t_begin + a.t_chunk);
+    if (t_begin >= t_end) return;
+
+    // the tile's weight chunks -> LDS (once per workgroup)
+    const int tile_c0 = a.gptr[tile * 16], tile_c1 = a.gptr[tile * 16 + 16];
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_c0 * 4;
+        f32x4* dst = reinterpret_cast<f32x4*>(wlds);
+        for (int i = tid; i < (tile_c1 - tile_c0) * 4; i += 1024) dst[i] = src[i];
+    }
+
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int grp = tile * 16 + wave;
+    const int c_begin = a.gptr[grp], c_end = a.gptr[grp + 1];
+    const int n_chunks = c_end - c_begin;
+    const int row0 = a.trow[tile] + wave * 4;
+    const int n_here = min(4, a.trow[tile + 1] - row0);
+    // constant address space => s_load (the offsets are wave-uniform and never written here)
+    typedef const int __attribute__((address_space(4))) cint;
+    cint* offs = (cint*)(a.goff + (long long)c_begin * 4);
+    const char* wmine = wlds + (c_begin - tile_c0) * 64 + (lane & 3) * 16;
+    const char* xmine = lds + lane * 4;
+
+    f32x4 stage[PASSES];
+    auto issue = [&](int t) {
+        const float* xt = a.src.x + (long long)t * a.src.xbs + f_base + li * 4;
+        const float* ht = a.src.xh + (long long)t * a.src.xhbs + f_base + li * 4;
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            if (p < n_pass) {
+                const float* b = (HALO && ((halo_mask >> p) & 1u)) ? ht : xt;
+                stage[p] = ld4(b + soff[p]);
+            }
+        }
+    };
+    issue(t_begin);
+
+    for (int t = t_begin; t < t_end; ++t) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p)
+            if (p < n_pass)
+                *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
+        __syncthreads();
+        if (t + 1 < t_end) issue(t + 1);
+
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (n_chunks > 0) {
+            int o0 = offs[0], o1 = offs[1], o2 = offs[2], o3 = offs[3];
+            for (int c = 0; c < n_chunks; ++c) {
+                const int p0 = o0, p1 = o1, p2 = o2, p3 = o3;
+                if (c + 1 < n_chunks) {
+                    cint* nx = offs + (long long)(c + 1) * 4;
+                    o0 = nx[0]; o1 = nx[1]; o2 = nx[2]; o3 = nx[3];
+                }
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(wmine + c * 64);
+                const float x0 = *reinterpret_cast<const float*>(xmine + p0);
+                const float x1 = *reinterpret_cast<const float*>(xmine + p1);
+                const float x2 = *reinterpret_cast<const float*>(xmine + p2);
+                const float x3 = *reinterpret_cast<const float*>(xmine + p3);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, x1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, x2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, x3, acc1, 0, 0, 0);
+            }
+        }
+        acc0 += acc1;
+        float* yp = a.Y + (long long)t * a.ybs + (long long)row0 * a.yrs + f_base + lane;
+        if (n_here > 0) yp[0] = acc0.x;
+        if (n_here > 1) yp[a.yrs] = acc0.y;
+        if (n_here > 2) yp[2 * a.yrs] = acc0.z;
+        if (n_here > 3) yp[3 * a.yrs] = acc0.w;
+        __syncthreads();
+    }
+}
+
+template <bool HALO>
+int launch_mfma(const MfmaArgs& a, hipStream_t s) {
+    const size_t lds_bytes = 160 * 1024;
+    auto kern = spmm_mfma<HALO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return sgp::fail((int)e, "spmm_mfma: LDS opt-in: %s", hipGetErrorString(e));
+    dim3 grid(a.n_tiles * a.n_tchunks, a.feat / 64);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, s, a);
+    return sgp::check_launch("spmm_mfma");
+}
+
 constexpr int kTiledThreads = 1024;
 constexpr int kTiledPasses = 8;
 constexpr int kTiledCapacity = kTiledPasses * kTiledThreads / 16;   // staged rows per tile
@@ -433,6 +585,51 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
     const int nb = max_row_edges <= 32 ? 2 : 8;
     hipStream_t s = (hipStream_t)stream;
     return Xh ? dispatch_tiled<true>(a, rpg, nb, s) : dispatch_tiled<false>(a, rpg, nb, s);
+}
+
+int32_t sgp_spmm_mfma_max_union(void) { return kMfmaPasses * 64; }
+int32_t sgp_spmm_mfma_max_chunks(void) { return kMfmaMaxChunks; }
+
+int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* ucol,
+                      const int32_t* gptr, const int32_t* goff, const float* gw,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_chunks,
+                      const float* X, int64_t xrs, int64_t xbs,
+                      const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
+                      float* Y, int64_t yrs, int64_t ybs,
+                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                      sgp_stream_t stream) {
+    SGP_REQUIRE(trow && uptr && ucol && gptr && goff && gw && X && Y, "sgp_spmm_mfma_f32: null pointer");
+    SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_chunks >= 0,
+                "sgp_spmm_mfma_f32: bad size");
+    {
+        const long long own = Xh ? n_own : n_cols, far = Xh ? n_cols - n_own : 0;
+        SGP_REQUIRE(n_cols >= 0 && own >= 0 && far >= 0 && own * xrs < (1ll << 31) && far * xhrs < (1ll << 31),
+                    "sgp_spmm_mfma_f32: row offsets exceed 32 bits (use sgp_spmm_csr_f32)");
+    }
+    if (n_rows == 0 || batch == 0 || feat == 0) return 0;
+    if (feat % 64 != 0)
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_mfma_f32: feat=%d is not a multiple of 64", feat);
+    if (max_union > kMfmaPasses * 64 || max_tile_chunks > kMfmaMaxChunks)
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_mfma_f32: tile working set (%d rows, %d chunks) exceeds LDS (%d, %d)",
+                         max_union, max_tile_chunks, kMfmaPasses * 64, kMfmaMaxChunks);
+    SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && sgp::aligned16(X) &&
+                (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh))) &&
+                sgp::aligned16(goff) && sgp::aligned16(gw),
+                "sgp_spmm_mfma_f32: strides/pointers must be 16-byte aligned");
+    MfmaArgs a;
+    a.trow = trow; a.uptr = uptr; a.ucol = ucol; a.gptr = gptr; a.goff = goff; a.gw = gw;
+    a.n_tiles = n_tiles;
+    a.src = Src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
+    a.Y = Y; a.yrs = yrs; a.ybs = ybs;
+    a.n_rows = n_rows; a.batch = batch; a.feat = feat;
+    const int nft = feat / 64;
+    long long want = (long long)batch * n_tiles * nft / 4096;
+    int tc = (int)(want < 16 ? 16 : want);
+    if (tc > batch) tc = batch;
+    a.t_chunk = tc;
+    a.n_tchunks = (batch + tc - 1) / tc;
+    hipStream_t s = (hipStream_t)stream;
+    return Xh ? launch_mfma<true>(a, s) : launch_mfma<false>(a, s);
 }
 
 }  // extern "C"

@@ -158,9 +158,13 @@ class ShiftOperator:
         """y[b] = A x[b] for strided [B, N, F] CUDA views (no allocation)."""
         from . import hip
         plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device)
-        if force == "tiled" and plan is None:
+        if force in ("tiled", "mfma") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
-        if plan is not None:
+        if plan is not None and force == "mfma":
+            if plan.gw is None:
+                raise NotImplementedError("no row-group stream for this plan")
+            hip.spmm_mfma(plan, x, y)
+        elif plan is not None:
             hip.spmm_tiled(plan, x, y)
         else:
             rowptr, col, val = self.device_csr(x.device)
@@ -202,12 +206,19 @@ class TilePlan:
     n_rows: int
     max_union: int
     max_row_edges: int
+    gptr: Optional[torch.Tensor] = None     # int32 [16 * n_tiles + 1], chunk ranges of the 4-row groups
+    group_fill: float = 0.0                 # useful / issued FMAs of the row-group stream
+    goff: Optional[torch.Tensor] = None     # int32 [n_chunks, 4]
+    gw: Optional[torch.Tensor] = None       # float32 [n_chunks, 4 rows, 4 steps]
+    max_tile_chunks: int = 0
 
     def to(self, device):
+        mv = lambda t: None if t is None else t.to(device)
         return TilePlan(self.trow.to(device), self.uptr.to(device), self.ucol.to(device),
                         self.erow.to(device), self.ecol.to(device), self.eval.to(device),
                         self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
-                        self.max_row_edges)
+                        self.max_row_edges, mv(self.gptr), self.group_fill,
+                        mv(self.goff), mv(self.gw), self.max_tile_chunks)
 
 
 def tile_unions(rowptr, col, trow):
@@ -251,8 +262,47 @@ def split_tiles(rowptr, col, n_rows, tile_rows, max_union, min_rows=8):
         trow = np.unique(np.concatenate([trow, mids]))
 
 
+GROUP_ROWS = 4          # rows per wave in sgp_spmm_mfma_f32
+GROUPS_PER_TILE = 16    # 16 waves per workgroup -> tiles of at most 64 rows
+
+
+def build_group_stream(trow, lcol, row_of_edge, val, row_bytes=256):
+    """Row-group stream of ``sgp_spmm_mfma_f32`` (include/sgp_amd.h): for every group of 4
+    consecutive rows of a tile, the sorted union of the rows' local column indices with the
+    four weights of each column (0 where a row lacks it), 4 steps per chunk."""
+    n_tiles = len(trow) - 1
+    n_rows = int(trow[-1])
+    tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
+    in_tile = np.arange(n_rows, dtype=np.int64) - trow[tile_of_row]
+    assert in_tile.max(initial=0) < GROUP_ROWS * GROUPS_PER_TILE
+    group_of_row = tile_of_row * GROUPS_PER_TILE + in_tile // GROUP_ROWS
+    slot_of_row = in_tile % GROUP_ROWS
+    n_groups = n_tiles * GROUPS_PER_TILE
+    g_e = group_of_row[row_of_edge]
+    key = g_e * 65536 + lcol
+    uniq, inv = np.unique(key, return_inverse=True)          # one entry per (group, column) step
+    g_s = uniq >> 16
+    counts = np.bincount(g_s, minlength=n_groups)
+    chunks = (counts + 3) // 4
+    gptr = np.zeros(n_groups + 1, dtype=np.int64)
+    gptr[1:] = np.cumsum(chunks)
+    first = np.zeros(n_groups + 1, dtype=np.int64)
+    first[1:] = np.cumsum(counts)
+    pos = gptr[g_s] * 4 + (np.arange(uniq.size, dtype=np.int64) - first[g_s])   # padded step index
+    n_steps = int(gptr[-1]) * 4
+    off = np.zeros(n_steps, dtype=np.int32)
+    off[pos] = ((uniq & 0xffff) * row_bytes).astype(np.int32)
+    w = np.zeros((n_steps, GROUP_ROWS), dtype=np.float32)
+    w[pos[inv], slot_of_row[row_of_edge]] = val
+    fill = float(lcol.size) / max(1, n_steps * GROUP_ROWS)
+    # offsets [chunk][step], weights [chunk][row][step]
+    goff = np.ascontiguousarray(off.reshape(-1, 4))
+    gw = np.ascontiguousarray(w.reshape(-1, 4, GROUP_ROWS).transpose(0, 2, 1))
+    return gptr.astype(np.int32), fill, goff, gw
+
+
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
-                    candidates=(128, 64, 32)) -> Optional[TilePlan]:
+                    candidates=(64, 32, 16)) -> Optional[TilePlan]:
     """Tallest tiling whose per-tile working set fits the LDS stage, or None when the
     graph has no locality to exploit (average tile would stage more than it reuses)."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -284,9 +334,15 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
         pos = erow[row_of_edge] + (np.arange(col.size, dtype=np.int64) - rowptr[row_of_edge])
         ecol[pos] = lcol.astype(np.uint16)
         evalv[pos] = val
-        return TilePlan(torch.from_numpy(trow.astype(np.int32)),
+        plan = TilePlan(torch.from_numpy(trow.astype(np.int32)),
                         torch.from_numpy(uptr.astype(np.int32)), torch.from_numpy(ucol),
                         torch.from_numpy(erow.astype(np.int32)),
                         torch.from_numpy(ecol.view(np.int16)), torch.from_numpy(evalv),
                         int(np.diff(trow).max()), n_tiles, int(n_rows), mu, mre)
+        if plan.tile_rows <= GROUP_ROWS * GROUPS_PER_TILE:
+            gptr, fill, goff, gw = build_group_stream(trow, lcol, row_of_edge, np.asarray(val))
+            plan.gptr, plan.group_fill = torch.from_numpy(gptr), fill
+            plan.goff, plan.gw = torch.from_numpy(goff), torch.from_numpy(gw)
+            plan.max_tile_chunks = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
+        return plan
     return None

@@ -34,6 +34,14 @@ SIGNATURES = {
                                           c_p, c_i64, c_i64, c_i32,
                                           c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p,
+                                         c_i32, c_i32, c_i32,
+                                         c_p, c_i64, c_i64,
+                                         c_p, c_i64, c_i64, c_i32,
+                                         c_p, c_i64, c_i64,
+                                         c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_mfma_max_union": (c_i32, []),
+    "sgp_spmm_mfma_max_chunks": (c_i32, []),
     "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
     "sgp_spmm_tiled_max_tile_rows": (c_i32, []),
     "sgp_spmm_tiled_max_row_edges": (c_i32, []),
@@ -172,10 +180,30 @@ def spmm_tiled(plan, x, y, halo=None, n_own=None):
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_tiled_f32")
 
 
+def spmm_mfma(plan, x, y, halo=None, n_own=None):
+    """Row-group product on the matrix cores (v_mfma_f32_4x4x1_16b_f32)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
+    _check(lib.sgp_spmm_mfma_f32(
+        plan.trow.data_ptr(), plan.uptr.data_ptr(), plan.ucol.data_ptr(),
+        plan.gptr.data_ptr(), plan.goff.data_ptr(), plan.gw.data_ptr(),
+        plan.n_tiles, plan.max_union, plan.max_tile_chunks,
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
+        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
+        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mfma_f32")
+
+
 def tiled_limits(feat):
+    """Plan limits that satisfy every LDS-staged kernel at once (one plan serves them all)."""
     lib = load()
-    return dict(max_union=lib.sgp_spmm_tiled_max_union(feat),
-                max_tile_rows=lib.sgp_spmm_tiled_max_tile_rows(),
+    return dict(max_union=min(lib.sgp_spmm_tiled_max_union(feat), lib.sgp_spmm_mfma_max_union()),
+                max_tile_rows=min(lib.sgp_spmm_tiled_max_tile_rows(), 64),
                 max_row_edges=lib.sgp_spmm_tiled_max_row_edges())
 
 

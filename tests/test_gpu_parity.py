@@ -73,7 +73,7 @@ def test_spmm_csr_strided_slots_in_place():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     buf = torch.randn(t, n, p * d, device="cuda")
     ref = buf.clone()
-    for force in ("csr", "tiled"):
+    for force in ("csr", "tiled", "mfma"):
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
@@ -93,9 +93,10 @@ def test_spmm_tiled_knn(n, k, feat):
     plan = op.tile_plan(feat, torch.device("cuda"))
     assert plan is not None
     x = torch.randn(5, n, feat)
-    y = torch.full((5, n, feat), float("nan"), device="cuda")
-    op.propagate(x.cuda(), y, force="tiled")
-    close(y, dense_ref(op, x))
+    for force in ("tiled", "mfma"):
+        y = torch.full((5, n, feat), float("nan"), device="cuda")
+        op.propagate(x.cuda(), y, force=force)
+        close(y, dense_ref(op, x))
     y2 = torch.empty_like(y)
     op.propagate(x.cuda(), y2, force="csr")
     close(y, y2, rtol=1e-6, atol=1e-6)
@@ -111,17 +112,18 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     op = graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n)
     assert op.tile_plan(feat, torch.device("cuda")) is not None
     x = torch.randn(t, n, feat)
-    y = torch.full((t, n, feat), float("nan"), device="cuda")
-    op.propagate(x.cuda(), y, force="tiled")
-    close(y, dense_ref(op, x))
-    assert float(y[:, ::7].abs().max()) == 0.0
+    for force in ("tiled", "mfma"):
+        y = torch.full((t, n, feat), float("nan"), device="cuda")
+        op.propagate(x.cuda(), y, force=force)
+        close(y, dense_ref(op, x))
+        assert float(y[:, ::7].abs().max()) == 0.0
 
 
 def test_spmm_traffic_graph_small_n_long_t():
     ei, ew = synthetic.sparse_traffic_graph(325, 2369, seed=2)
     op = graph.ShiftOperator.from_edges(ei, ew, 325)
     x = torch.randn(600, 325, 128)
-    for force in ("csr", "tiled"):
+    for force in ("csr", "tiled", "mfma"):
         y = torch.empty(600, 325, 128, device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -311,7 +313,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("tiled", "csr"):
+    for force in ("mfma", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity

@@ -1,0 +1,208 @@
+"""bench.py -- the driver's benchmark contract for the SGP encoder hot path on MI355X.
+
+One "step" = one full pass of the training-free encoder (leaky reservoir over T steps, then K
+hops of graph-shift propagation) over a synthetic batch that is already resident in HBM.
+Default workload = the target line of BASELINE.json's north_star / BASELINE.md 3:
+N = 100 000 nodes, 100-NN geometric graph (Morton order), T = 1024, F_in = 64, reservoir 64 x 1,
+K = 4  ->  D_out = 320, 131 GB of output, 157 GB resident.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c3|c2|small]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 the SAME graph is node-partitioned across the ranks (strong scaling): reservoir
+local, one all_to_all of halo rows per hop over RCCL.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import sgp_amd  # noqa: E402
+from sgp_amd import hip, partition, synthetic  # noqa: E402
+from sgp_amd.sgp_preprocessing import spatial_operators  # noqa: E402
+
+WORKLOADS = {
+    # name: N, T, F_in, R, L, K, bidirectional, global_attr, graph
+    "target": dict(N=100000, T=1024, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
+    "c3": dict(N=10000, T=2016, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
+    "c2": dict(N=325, T=52116, F=3, R=128, L=1, K=4, bidir=True, glob=True, graph="traffic"),
+    "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=False, glob=False, graph="knn100"),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def build_graph(w):
+    if w["graph"] == "knn100":
+        ei, ew, _ = synthetic.knn_graph(w["N"], 100, seed=1)
+    else:
+        ei, ew = synthetic.sparse_traffic_graph(w["N"], 2369, seed=1)
+    return ei, ew
+
+
+def hop_bytes(n, t, d, nnz):
+    """Algorithmic HBM bytes of one hop: X read once, Y written once, CSR once."""
+    return 2 * n * t * d * 4 + nnz * 8 + (n + 1) * 4
+
+
+def cpu_baseline(w, seconds_budget=10.0):
+    """The CPU oracle (same op sequence as the reference) timed on this box's host cores on a
+    bounded sample of the workload: same F/R/K/graph family, fewer nodes and steps.  The number
+    of steps is calibrated so that the whole leg stays within ~seconds_budget."""
+    from oracle import sgp_oracle as O
+    threads = min(os.cpu_count() or 1, 32)       # more threads only add dispatch overhead here
+    torch.set_num_threads(threads)
+    n = min(w["N"], 20000)
+    ei, ew = build_graph(dict(w, N=n))
+    torch.manual_seed(42)
+    layers = O.init_reservoir(w["F"], w["R"], num_layers=w["L"], leaking_rate=0.9,
+                              spectral_radius=0.9, density=0.7)
+    ops = O.shift_operators_csr(ei, ew, n, bidirectional=w["bidir"])   # graph prep: not timed
+
+    def run(t):
+        x = torch.randn(t, n, w["F"])
+        t0 = time.time()
+        O.encoder_forward_prebuilt(x, ops, layers, w["K"], global_attr=w["glob"])
+        return time.time() - t0
+
+    run(1)                                        # warm-up (thread pool, operator build)
+    probe = run(2) / 2                            # seconds per step
+    t = int(max(2, min(w["T"], 32, seconds_budget / 3 / max(probe, 1e-6))))
+    best = min(run(t), run(t))
+    return {"value": n * t / best, "unit": "node-steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/sgp_oracle.py encoder on N={n} nodes x T={t} steps of the same "
+                      f"workload (F={w['F']}, R={w['R']}, K={w['K']}, {w['graph']}), best of 2"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with "
+                         f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    hip.require_gpu()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    w = WORKLOADS[args.workload]
+    N, T, F, R, L, K = w["N"], w["T"], w["F"], w["R"], w["L"], w["K"]
+    ei, ew = build_graph(w)
+    ops = spatial_operators(ei, ew, N, bidirectional=w["bidir"])
+    nnz = ops[0].nnz()
+
+    torch.manual_seed(42)                                   # same weights on every rank
+    enc = sgp_amd.SGPEncoder(input_size=F, reservoir_size=R, reservoir_layers=L,
+                             leaking_rate=0.9, spectral_radius=0.9, density=0.7,
+                             input_scaling=1., receptive_field=K, bidirectional=w["bidir"],
+                             alpha_decay=False, global_attr=w["glob"])
+    d_h = enc.reservoir.output_size
+    if world > 1:
+        spatial, bounds = partition.make_partitioned_spatial(ops, K, w["glob"])
+        lo, hi = bounds[rank], bounds[rank + 1]
+        local_ops = [b.op for b in spatial.blocks]
+    else:
+        spatial, lo, hi = None, 0, N
+        local_ops = ops
+    n_own = hi - lo
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(T, n_own, F, device=dev, generator=g)   # synthetic, resident in HBM
+    out = torch.empty(T, n_own, enc.output_size, device=dev)
+    for o in local_ops:                                     # plans + device CSR built once
+        o.tile_plan(d_h, dev)
+        o.device_csr(dev)
+
+    hop_ms = []
+
+    def step(timed):
+        enc.reservoir.encode_into(x, out[:, :, :d_h])
+        if world == 1:
+            # hops launched one by one so each can be bracketed by HIP events on its stream
+            for d, op in enumerate(ops):
+                src = out[:, :, :d_h]
+                for h in range(K):
+                    s = 1 + d * K + h
+                    dst = out[:, :, s * d_h:(s + 1) * d_h]
+                    if timed:
+                        a, b = hip.Event(), hip.Event()
+                        a.record()
+                    op.propagate(src, dst)
+                    if timed:
+                        b.record()
+                        hop_ms.append((a, b))
+                    src = dst
+            if w["glob"]:
+                p = enc.sgp_encoder.num_blocks() - 1
+                hip.node_mean_bcast(out[:, :, :d_h], out[:, :, p * d_h:(p + 1) * d_h])
+        else:
+            spatial.encode_into(out, d_h)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = N * T * args.steps / elapsed
+        rec = {
+            "metric": "encoded node-steps/sec", "value": value, "unit": "node-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: N={N} nodes, T={T} steps, F_in={F}, "
+                                   f"reservoir {R}x{L}, K={K}, "
+                                   f"{'100-NN geometric graph (Morton order)' if w['graph'] == 'knn100' else 'traffic-like sparse graph'}"
+                                   f"{', bidirectional' if w['bidir'] else ''}"
+                                   f"{', global_attr' if w['glob'] else ''}",
+                       "nnz": nnz, "d_out": enc.output_size,
+                       "partition": f"{world} contiguous node block(s)"},
+        }
+        if hop_ms:
+            per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
+            bts = hop_bytes(N, T, d_h, nnz)
+            achieved = bts / (per_launch * 1e-3) / 1e9
+            plan = ops[0].tile_plan(d_h, dev)
+            rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": "spmm_tiled" if plan is not None else "spmm_csr_rows",
+                               "ms_per_launch": per_launch, "algorithmic_bytes": bts}
+        if not args.no_cpu_baseline and world == 1:
+            rec["cpu_baseline"] = cpu_baseline(w)
+        print(json.dumps(rec), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -46,11 +46,14 @@ class ShiftOperator:
     SpMM for a CUDA tensor ``x[..., N, F]`` (the reference's ``adj @ x``,
     ``lib/sgp_preprocessing.py:202``)."""
 
-    def __init__(self, rowptr, col, val, num_nodes):
+    def __init__(self, rowptr, col, val, num_nodes, num_cols=None):
         self.rowptr = rowptr.to(torch.int32).contiguous()
         self.col = col.to(torch.int32).contiguous()
         self.val = val.to(torch.float32).contiguous()
-        self.num_nodes = int(num_nodes)
+        self.num_nodes = int(num_nodes)            # rows (= nodes owned by this operator)
+        # columns; > num_nodes for the local block of a node partition, whose columns
+        # num_nodes .. num_cols-1 address halo rows received from peer GPUs
+        self.num_cols = int(num_nodes if num_cols is None else num_cols)
         self._dev = {}
         self._plans = {}
 
@@ -103,10 +106,10 @@ class ShiftOperator:
 
     # ---- duck-typed accessors (torch_sparse.SparseTensor-like) -------------
     def size(self, dim):
-        return self.num_nodes
+        return self.num_nodes if dim == 0 else self.num_cols
 
     def sparse_sizes(self):
-        return (self.num_nodes, self.num_nodes)
+        return (self.num_nodes, self.num_cols)
 
     def nnz(self):
         return int(self.col.numel())
@@ -121,7 +124,7 @@ class ShiftOperator:
 
     def to_dense(self):
         row, col, val = self.coo()
-        a = torch.zeros(self.num_nodes, self.num_nodes, dtype=torch.float32)
+        a = torch.zeros(self.num_nodes, self.num_cols, dtype=torch.float32)
         a.index_put_((row, col), val, accumulate=True)
         return a
 
@@ -154,21 +157,28 @@ class ShiftOperator:
             self._plans[key] = plan
         return self._plans[key]
 
-    def propagate(self, x, y, force=None):
-        """y[b] = A x[b] for strided [B, N, F] CUDA views (no allocation)."""
+    def propagate(self, x, y, force=None, halo=None):
+        """y[b] = A [x[b]; halo[b]] for strided [B, N, F] CUDA views (no allocation).
+        ``halo[B, num_cols - num_nodes, F]`` (any strides) supplies the columns past the
+        owned rows for the local block of a node partition."""
         from . import hip
+        if (halo is None) != (self.num_cols == self.num_nodes):
+            raise ValueError("halo rows are required exactly when num_cols > num_nodes")
         plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device)
+        if plan is not None and halo is not None and \
+                halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 31:
+            plan = None                      # tiled kernels use 32-bit row offsets
         if force in ("tiled", "mfma") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
         if plan is not None and force == "mfma":
             if plan.gw is None:
                 raise NotImplementedError("no row-group stream for this plan")
-            hip.spmm_mfma(plan, x, y)
+            hip.spmm_mfma(plan, x, y, halo, self.num_nodes)
         elif plan is not None:
-            hip.spmm_tiled(plan, x, y)
+            hip.spmm_tiled(plan, x, y, halo, self.num_nodes)
         else:
             rowptr, col, val = self.device_csr(x.device)
-            hip.spmm_csr(rowptr, col, val, x, y)
+            hip.spmm_csr(rowptr, col, val, x, y, halo, self.num_nodes)
         return y
 
     def __matmul__(self, x):

@@ -1,0 +1,190 @@
+"""Node-partitioned encoder across the GPUs of one node.
+
+The reference is single-process; the encoder nevertheless shards naturally:
+
+* reservoir: every node's recurrence is independent (``reservoir.py:166`` flattens
+  ``(b n)``), so rank g runs rows ``[lo_g, hi_g)`` with no communication;
+* hop k: rank g computes its rows of ``A . X`` and needs ``X[:, c, :]`` for every column its
+  rows reference -- owned columns are local, the rest ("halo") are fetched from their owners
+  with ONE ``all_to_all_single`` per hop over RCCL/xGMI (point-to-point links: every peer's
+  rows travel their own link, nothing is relayed);
+* ``global_attr``: ``all_reduce(sum)`` of the ``[T, D_h]`` partial column sums.
+
+One process per GPU; ``torch.distributed`` supplies the process group (``nccl`` == RCCL on
+ROCm, ``gloo`` in the CPU tests).  Device work goes through an ``ops`` object -- the HIP
+binding by default.  The CPU tests substitute a plain-torch stand-in for it so that the
+partition / halo / collective logic is exercised with world_size 2 on a box without GPUs;
+that stand-in lives in ``tests/`` and is never used by the product.
+"""
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import hip
+from .graph import ShiftOperator
+
+
+def partition_bounds(n_nodes, world_size, rowptr=None):
+    """Contiguous row blocks: equal rows, or equal nnz when a CSR ``rowptr`` is given."""
+    if rowptr is None:
+        return [(n_nodes * r) // world_size for r in range(world_size + 1)]
+    rp = np.asarray(rowptr, dtype=np.int64)
+    targets = (rp[-1] * np.arange(1, world_size)) / world_size
+    cuts = np.searchsorted(rp, targets, side="left")
+    return [0] + [int(c) for c in cuts] + [int(n_nodes)]
+
+
+@dataclass
+class LocalBlock:
+    """Rows ``[lo, hi)`` of a global operator, columns renumbered ``[owned | halo]``."""
+    op: ShiftOperator                 # hi-lo rows, (hi-lo) + n_halo columns
+    lo: int
+    hi: int
+    halo_global: torch.Tensor         # int64 [n_halo] global ids of the halo columns (sorted)
+    recv_counts: List[int]            # halo rows owned by each peer (contiguous in halo order)
+    send_index: torch.Tensor          # int32 [sum(send_counts)] LOCAL row ids, peer-major
+    send_counts: List[int]            # rows each peer needs from me
+
+    @property
+    def n_own(self):
+        return self.hi - self.lo
+
+    @property
+    def n_halo(self):
+        return int(self.halo_global.numel())
+
+
+def _halo_of(op, lo, hi):
+    rp = op.rowptr.long()
+    cols = op.col[rp[lo]:rp[hi]].long()
+    outside = cols[(cols < lo) | (cols >= hi)]
+    return torch.unique(outside, sorted=True), cols
+
+
+def split_operator(op: ShiftOperator, bounds, rank) -> LocalBlock:
+    """Local block of ``rank`` plus the halo bookkeeping, computed from the full operator
+    (every rank holds the whole graph: it is tiny next to the node features)."""
+    world = len(bounds) - 1
+    lo, hi = bounds[rank], bounds[rank + 1]
+    halo, cols = _halo_of(op, lo, hi)
+    n_own = hi - lo
+    own = (cols >= lo) & (cols < hi)
+    local = torch.where(own, cols - lo, n_own + torch.searchsorted(halo, cols))
+    rp = op.rowptr.long()
+    rowptr = rp[lo:hi + 1] - rp[lo]
+    vals = op.val[rp[lo]:rp[hi]]
+    block = ShiftOperator(rowptr, local, vals, n_own, num_cols=n_own + int(halo.numel()))
+    b = torch.tensor(bounds)
+    owner = torch.bucketize(halo, b[1:], right=True)                # rank owning each halo column
+    recv_counts = torch.bincount(owner, minlength=world).tolist()
+    send_idx, send_counts = [], []
+    for p in range(world):                                          # what does p need from me?
+        if p == rank:
+            send_counts.append(0)
+            continue
+        ph, _ = _halo_of(op, bounds[p], bounds[p + 1])
+        mine = ph[(ph >= lo) & (ph < hi)] - lo
+        send_idx.append(mine)
+        send_counts.append(int(mine.numel()))
+    send_index = (torch.cat(send_idx) if send_idx else torch.zeros(0, dtype=torch.long)).int()
+    return LocalBlock(block, lo, hi, halo, recv_counts, send_index, send_counts)
+
+
+class HipOps:
+    """Device operations of the partitioned encoder on the MI355X (the product path)."""
+
+    @staticmethod
+    def gather_nodes(x, index, out):
+        return hip.gather_nodes(x, index, out)
+
+    @staticmethod
+    def propagate(op, x, y, halo):
+        return op.propagate(x, y, halo=halo)
+
+    @staticmethod
+    def node_sums(x):
+        return hip.node_sums(x)
+
+    @staticmethod
+    def bcast_rows(src, scale, y):
+        return hip.bcast_rows(src, scale, y)
+
+
+class HaloExchange:
+    """Per-hop exchange of the rows peers reference.  Buffers are ``[rows, T, D]`` so that
+    ``all_to_all_single`` splits them along dim 0; the SpMM reads the receive buffer in place
+    through its (row, batch) strides."""
+
+    def __init__(self, block: LocalBlock, group=None, ops=HipOps):
+        self.block, self.group, self.ops = block, group, ops
+        self._send = self._recv = None
+        self._idx = None
+
+    def _buffers(self, T, D, device):
+        shape_s = (sum(self.block.send_counts), T, D)
+        shape_r = (self.block.n_halo, T, D)
+        if self._send is None or self._send.shape != shape_s or self._send.device != device:
+            self._send = torch.empty(shape_s, dtype=torch.float32, device=device)
+            self._recv = torch.empty(shape_r, dtype=torch.float32, device=device)
+            self._idx = self.block.send_index.to(device)
+        return self._send, self._recv
+
+    def __call__(self, x):
+        """x[T, n_own, D] (strided view) -> halo[T, n_halo, D] view of the receive buffer."""
+        T, _, D = x.shape
+        send, recv = self._buffers(T, D, x.device)
+        if send.shape[0]:
+            self.ops.gather_nodes(x, self._idx, send.permute(1, 0, 2))
+        dist.all_to_all_single(recv, send, output_split_sizes=self.block.recv_counts,
+                               input_split_sizes=self.block.send_counts, group=self.group)
+        return recv.permute(1, 0, 2)
+
+
+class PartitionedSpatial:
+    """K-hop propagation + global mean of ``SGPSpatialEncoder.encode_into`` for the local
+    node block: fills ``out[T, n_own, P * feat]`` in place (block 0 already written)."""
+
+    def __init__(self, blocks: List[LocalBlock], receptive_field, global_attr, n_total,
+                 group=None, ops=HipOps):
+        self.blocks = blocks                       # forward (+ backward) local blocks
+        self.k, self.global_attr, self.n_total = receptive_field, global_attr, n_total
+        self.group, self.ops = group, ops
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.exchanges = [HaloExchange(b, group, ops) for b in blocks]
+
+    def num_blocks(self):
+        return 1 + len(self.blocks) * self.k + (1 if self.global_attr else 0)
+
+    def encode_into(self, out, feat):
+        for d, (blk, xchg) in enumerate(zip(self.blocks, self.exchanges)):
+            src = out[:, :, 0:feat]
+            for h in range(self.k):
+                s = 1 + d * self.k + h
+                dst = out[:, :, s * feat:(s + 1) * feat]
+                # every rank enters the collective, even one whose block has no halo
+                halo = xchg(src) if self.world_size > 1 else None
+                self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
+                src = dst
+        if self.global_attr:
+            p = self.num_blocks() - 1
+            sums = self.ops.node_sums(out[:, :, :feat])
+            if self.world_size > 1:
+                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+            self.ops.bcast_rows(sums, 1.0 / self.n_total, out[:, :, p * feat:(p + 1) * feat])
+        return out
+
+
+def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
+                             rank=None, world_size=None, group=None, ops=HipOps,
+                             balance="rows"):
+    """Split the forward (and backward) global operators for this rank."""
+    rank = dist.get_rank(group) if rank is None else rank
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    n = ops_global[0].num_nodes
+    bounds = partition_bounds(n, world_size,
+                              ops_global[0].rowptr.numpy() if balance == "nnz" else None)
+    blocks = [split_operator(op, bounds, rank) for op in ops_global]
+    return PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops), bounds

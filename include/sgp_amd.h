@@ -100,19 +100,23 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
                        sgp_stream_t stream);
 /* Matrix-core row-group kernel.  Tiles and their distinct-column lists (tile_row_ptr / uptr /
  * ucol) are as above with tiles of at most 64 rows.  Every tile is cut into 16 groups of 4
- * consecutive rows (group g of tile k = rows tile_row_ptr[k] + 4g ..); a group walks the sorted
- * union of its rows' columns in "steps", 4 steps per chunk, tail steps padded with offset 0 /
- * weight 0; gptr[k * 16 + g] .. gptr[k * 16 + g + 1] is the group's chunk range.  The 4-row x
- * 64-feature outer product of every step is one v_mfma_f32_4x4x1_16b_f32 (exact fp32):
- *   goff[chunk][4]          LDS byte offset (index in the tile's ucol list * 256) of each step
- *                           (read through the scalar cache)
- *   gw[chunk][row][step]    weights, 0 where the row has no such column (copied to LDS once
- *                           per workgroup)
- * Limits: sgp_spmm_mfma_max_union() staged rows per tile, sgp_spmm_mfma_max_chunks() chunks
- * per tile. */
+ * rows (slots 4g .. 4g+3 of the tile, see rowmap).  A group's sorted column
+ * union is dealt round-robin to 4 classes q; super-step s handles the s-th column of every
+ * class with one v_mfma_f32_4x4x1_16b_f32 per feature (exact fp32).  The stream is stored 4
+ * super-steps ("quad") at a time, gptr[k * 16 + g] .. gptr[k * 16 + g + 1] = quad range:
+ *   gw  [quad][q][row i][4]   float   weight of row i for class q's column in super-steps 0..3
+ *                                     of the quad (0 = row lacks the column / padding)
+ *   gidx[quad][q][4]          uint16  index of that column in the tile's ucol list (0 = padding)
+ *   gsteps[k * 16 + g]        int32   super-steps of the group (= ceil(columns / 4) <= 4 * quads)
+ *   rowmap[64 * k + 4 g + i]  int32   output row of slot i of group g of tile k, -1 = empty
+ *                                     (the host may permute rows inside a tile so that the 4
+ *                                     rows of a group share most of their columns)
+ * Limits: sgp_spmm_mfma_max_union() staged rows per tile, sgp_spmm_mfma_max_quads() quads per
+ * tile (weights and indices are LDS-resident). */
 int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
-                      const int32_t* gptr, const int32_t* goff, const float* gw,
-                      int32_t n_tiles, int32_t max_union, int32_t max_tile_chunks,
+                      const int32_t* gptr, const uint16_t* gidx, const float* gw,
+                      const int32_t* rowmap, const int32_t* gsteps,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                       const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
                       int32_t n_own,
@@ -120,7 +124,7 @@ int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const in
                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                       sgp_stream_t stream);
 int32_t sgp_spmm_mfma_max_union(void);
-int32_t sgp_spmm_mfma_max_chunks(void);
+int32_t sgp_spmm_mfma_max_quads(void);
 
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and

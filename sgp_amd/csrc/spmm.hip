@@ -294,21 +294,31 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     }
 }
 
+int tiled_variant();
+
 // ---------------------------------------------------------------- MFMA row-group kernel
 // Same tile staging as spmm_tiled, different inner product: a wave owns FOUR consecutive output
 // rows ("row group") and walks the sorted union of their columns.  v_mfma_f32_4x4x1_16b_f32
-// performs 16 independent 4x1 (x) 1x4 outer products per instruction -- exactly "4 output rows
-// (A = their weights for one source column) times 64 features (B = the staged source row, one
-// float per lane)".  The
-// accumulator (4 VGPRs) holds rows 0..3 of the group for feature = lane.  Exact fp32 FMAs, so
-// numerics equal the VALU kernels.  Per step the VALU only forms one LDS address; weights come
-// from an LDS-resident copy of the group's stream (one ds_read_b128 per 4 steps, lane (b, i)
-// reads row i's weights), offsets arrive as SGPRs through the scalar cache.
-//   goff  [n_chunks][4]      int32  byte offset of the staged row of each step
-//   gw    [n_chunks][4][4]   float  w[row i][step] of the chunk
+// performs 16 independent 4x1 (x) 1x4 outer products per instruction: A = the 4 rows' weights for
+// one source column, B = 4 features of that column's staged row.  Exact fp32 FMAs, so numerics
+// equal the VALU kernels.
+//
+// Lane l = (q = l >> 4, li = l & 15).  The group's columns are dealt round-robin to 4 classes q;
+// per "super-step" every class fetches 16 bytes (features 4 li .. 4 li + 3) of ITS column with one
+// ds_read_b128 -- full LDS rate, 4 different staged rows per wave instruction, conflict-free --
+// and issues 4 MFMAs (one per feature m of the 16 bytes): MFMA block b = l >> 2 pairs the weights
+// w[row i = l & 3] of class q's column with feature 4 li + m.  Accumulator m, register i, lane l
+// = partial y[row i][4 li + m] over class q's columns; once per time step the 4 classes are
+// summed across lanes (l ^ 16, l ^ 32) and class q stores row q as one float4 per lane.
+// Weights and row indices are an LDS-resident copy of the group's stream, read 4 super-steps at
+// a time (one ds_read_b128 + one ds_read_b64 per 16 MFMAs); the VALU only forms addresses.
+//   gw   [quad][q][i][4]  float   weight of row i for class q's column in super-steps 4*quad + 0..3
+//   gidx [quad][q][4]     uint16  index of that column in the tile's staged list
+// (0 / weight 0 padding), gptr[16 * tile + g] .. = quad range of group g.
 struct MfmaArgs {
     const int* trow; const int* uptr; const int* ucol;
-    const int* gptr; const int* goff; const float* gw;
+    const int* gptr; const unsigned short* gidx; const float* gw; const int* rowmap;
+    const int* gsteps;
     int n_tiles;
     Src src;
     float* Y; long long yrs, ybs;
@@ -318,20 +328,20 @@ struct MfmaArgs {
 
 constexpr int kMfmaPasses = 7;                       // 448 staged rows
 constexpr int kMfmaStageBytes = kMfmaPasses * 64 * 256;
-constexpr int kMfmaMaxChunks = (160 * 1024 - kMfmaStageBytes) / 64;   // LDS-resident weight chunks per tile
+constexpr int kMfmaQuadBytes = 256 + 32;             // weights + indices of 4 super-steps
+constexpr int kMfmaMaxQuads = (160 * 1024 - kMfmaStageBytes) / kMfmaQuadBytes;
 
-template <bool HALO>
+template <bool HALO, int ABL = 0>
 __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int PASSES = kMfmaPasses;
     constexpr int FT = 64;
     constexpr int RPP = 64;
-    char* wlds = lds + kMfmaStageBytes;
 
     const int nwg = a.n_tiles * a.n_tchunks;
     const int orig = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
-    const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+    const int w = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
     const int tile = w % a.n_tiles;
     const int tchunk = w / a.n_tiles;
     const int f_base = blockIdx.y * FT;
@@ -361,82 +371,143 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
     const int t_end = min(a.batch, t_begin + a.t_chunk);
     if (t_begin >= t_end) return;
 
-    // the tile's weight chunks -> LDS (once per workgroup)
-    const int tile_c0 = a.gptr[tile * 16], tile_c1 = a.gptr[tile * 16 + 16];
+    // the tile's stream -> LDS (once per workgroup): weights then indices
+    const int tile_q0 = a.gptr[tile * 16], tile_q1 = a.gptr[tile * 16 + 16];
+    const int tile_quads = tile_q1 - tile_q0;
+    char* wlds = lds + kMfmaStageBytes;
+    char* ilds = wlds + tile_quads * 256;
     {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_c0 * 4;
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
         f32x4* dst = reinterpret_cast<f32x4*>(wlds);
-        for (int i = tid; i < (tile_c1 - tile_c0) * 4; i += 1024) dst[i] = src[i];
+        for (int i = tid; i < tile_quads * 16; i += 1024) dst[i] = src[i];
+        const f32x4* isrc = reinterpret_cast<const f32x4*>(a.gidx) + (long long)tile_q0 * 2;
+        f32x4* idst = reinterpret_cast<f32x4*>(ilds);
+        for (int i = tid; i < tile_quads * 2; i += 1024) idst[i] = isrc[i];
     }
 
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = tid >> 6;
     const int lane = tid & 63;
+    const int q = lane >> 4;
     const int grp = tile * 16 + wave;
-    const int c_begin = a.gptr[grp], c_end = a.gptr[grp + 1];
-    const int n_chunks = c_end - c_begin;
-    const int row0 = a.trow[tile] + wave * 4;
-    const int n_here = min(4, a.trow[tile + 1] - row0);
-    // constant address space => s_load (the offsets are wave-uniform and never written here)
-    typedef const int __attribute__((address_space(4))) cint;
-    cint* offs = (cint*)(a.goff + (long long)c_begin * 4);
-    const char* wmine = wlds + (c_begin - tile_c0) * 64 + (lane & 3) * 16;
-    const char* xmine = lds + lane * 4;
+    const int q_begin = a.gptr[grp] - tile_q0, n_quads = a.gptr[grp + 1] - a.gptr[grp];
+    const int n_super = a.gsteps[grp];                     // super-steps actually used
+    const int my_row = a.rowmap[tile * 64 + wave * 4 + q];   // output row of class q (-1: none)
+    const char* wmine = wlds + q_begin * 256 + (q * 4 + (lane & 3)) * 16;
+    const char* imine = ilds + q_begin * 32 + q * 8;
+    const char* xmine = lds + li * 16;
 
     f32x4 stage[PASSES];
-    auto issue = [&](int t) {
-        const float* xt = a.src.x + (long long)t * a.src.xbs + f_base + li * 4;
-        const float* ht = a.src.xh + (long long)t * a.src.xhbs + f_base + li * 4;
-#pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
-            if (p < n_pass) {
-                const float* b = (HALO && ((halo_mask >> p) & 1u)) ? ht : xt;
-                stage[p] = ld4(b + soff[p]);
-            }
+    // one staged row of step t per call: the prefetch is spread over the quad loop so the 7
+    // global loads per thread never queue up in front of the compute (in-order issue)
+    auto issue_one = [&](int t, int p) {
+        if constexpr (ABL >= 4) return;
+        if (p < n_pass) {
+            const bool far = HALO && ((halo_mask >> p) & 1u);
+            const float* b = far ? a.src.xh + (long long)t * a.src.xhbs
+                                 : a.src.x + (long long)t * a.src.xbs;
+            stage[p] = ld4(b + f_base + li * 4 + soff[p]);
         }
     };
-    issue(t_begin);
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) issue_one(t_begin, p);
 
     for (int t = t_begin; t < t_end; ++t) {
+        if constexpr (ABL < 4) {
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p)
-            if (p < n_pass)
-                *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
-        __syncthreads();
-        if (t + 1 < t_end) issue(t + 1);
-
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (n_chunks > 0) {
-            int o0 = offs[0], o1 = offs[1], o2 = offs[2], o3 = offs[3];
-            for (int c = 0; c < n_chunks; ++c) {
-                const int p0 = o0, p1 = o1, p2 = o2, p3 = o3;
-                if (c + 1 < n_chunks) {
-                    cint* nx = offs + (long long)(c + 1) * 4;
-                    o0 = nx[0]; o1 = nx[1]; o2 = nx[2]; o3 = nx[3];
-                }
-                const f32x4 wv = *reinterpret_cast<const f32x4*>(wmine + c * 64);
-                const float x0 = *reinterpret_cast<const float*>(xmine + p0);
-                const float x1 = *reinterpret_cast<const float*>(xmine + p1);
-                const float x2 = *reinterpret_cast<const float*>(xmine + p2);
-                const float x3 = *reinterpret_cast<const float*>(xmine + p3);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.x, x0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.y, x1, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.z, x2, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wv.w, x3, acc1, 0, 0, 0);
-            }
+            for (int p = 0; p < PASSES; ++p)
+                if (p < n_pass)
+                    *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
         }
-        acc0 += acc1;
-        float* yp = a.Y + (long long)t * a.ybs + (long long)row0 * a.yrs + f_base + lane;
-        if (n_here > 0) yp[0] = acc0.x;
-        if (n_here > 1) yp[a.yrs] = acc0.y;
-        if (n_here > 2) yp[2 * a.yrs] = acc0.z;
-        if (n_here > 3) yp[3 * a.yrs] = acc0.w;
-        __syncthreads();
+        if constexpr (ABL != 9) __syncthreads();
+        const bool more = t + 1 < t_end;
+
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        f32x4 wn = f32x4{0.f, 0.f, 0.f, 0.f};
+        uint2 in = uint2{0u, 0u};
+        if (n_quads > 0) {
+            wn = *reinterpret_cast<const f32x4*>(wmine);
+            in = *reinterpret_cast<const uint2*>(imine);
+        }
+#define SGP_SUPER(W, IDX)                                                                       \
+        {                                                                                       \
+            f32x4 xv;                                                                           \
+            if constexpr (ABL == 6) { const float f = __int_as_float((int)(IDX)); xv = f32x4{f, f, f, f}; } \
+            else xv = *reinterpret_cast<const f32x4*>(xmine + ((IDX) << 8));                    \
+            if constexpr (ABL == 5) {                                                           \
+                asm volatile("" :: "v"(xv.x), "v"(xv.y), "v"(xv.z), "v"(xv.w), "v"(W));        \
+            } else {                                                                            \
+                acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, xv.x, acc0, 0, 0, 0);              \
+                acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, xv.y, acc1, 0, 0, 0);              \
+                acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, xv.z, acc2, 0, 0, 0);              \
+                acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, xv.w, acc3, 0, 0, 0);              \
+            }                                                                                   \
+        }
+#define SGP_QUAD(C)                                                                             \
+        {                                                                                       \
+            const f32x4 wv = wn;                       /* the next quad's stream is fetched */  \
+            const uint2 ix = in;                       /* under this quad's MFMAs */            \
+            if ((C) + 1 < n_quads) {                                                            \
+                wn = *reinterpret_cast<const f32x4*>(wmine + ((C) + 1) * 256);                  \
+                in = *reinterpret_cast<const uint2*>(imine + ((C) + 1) * 32);                   \
+            }                                                                                   \
+            const int left = n_super - 4 * (C);        /* super-steps left (wave-uniform) */    \
+            SGP_SUPER(wv.x, ix.x & 0xffffu)                                                     \
+            if (left > 1) SGP_SUPER(wv.y, ix.x >> 16)                                           \
+            if (left > 2) SGP_SUPER(wv.z, ix.y & 0xffffu)                                       \
+            if (left > 3) SGP_SUPER(wv.w, ix.y >> 16)                                           \
+        }
+        // first PASSES quads carry one prefetch load each; the rest run in a plain loop
+        if constexpr (ABL != 8 && ABL != 9) {
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) {
+            if (more) issue_one(t + 1, p);
+            if (p < n_quads) SGP_QUAD(p)
+        }
+        for (int c = PASSES; c < n_quads; ++c) SGP_QUAD(c)
+        }
+#undef SGP_QUAD
+#undef SGP_SUPER
+        // sum the 4 column classes; class q keeps row q.  Two VALU-only exchange rounds:
+        // v_permlane16_swap trades the odd 16-lane rows of one register with the even rows of
+        // another (classes q <-> q ^ 1), v_permlane32_swap trades the wave halves (q <-> q ^ 2);
+        // swap + add leaves every lane with the sum it has to keep.
+        f32x4 out;
+        if constexpr (ABL == 7) {
+            out = acc0 + acc1 + acc2 + acc3;
+        } else {
+#define SGP_FOLD(ACC, DST)                                                                       \
+            {                                                                                   \
+                /* rows 0/1 of the group: even classes keep .x, odd keep .y; rows 2/3: .z/.w */  \
+                auto p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.x), __float_as_uint(ACC.y), false, false); \
+                auto p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.z), __float_as_uint(ACC.w), false, false); \
+                const float r01 = __uint_as_float(p01[0]) + __uint_as_float(p01[1]);            \
+                const float r23 = __uint_as_float(p23[0]) + __uint_as_float(p23[1]);            \
+                auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r01), __float_as_uint(r23), false, false); \
+                DST = __uint_as_float(h[0]) + __uint_as_float(h[1]);                            \
+            }
+            SGP_FOLD(acc0, out.x) SGP_FOLD(acc1, out.y) SGP_FOLD(acc2, out.z) SGP_FOLD(acc3, out.w)
+#undef SGP_FOLD
+        }
+        if (my_row >= 0)
+            st4(a.Y + (long long)t * a.ybs + (long long)my_row * a.yrs + f_base + li * 4, out);
+        if constexpr (ABL != 9) __syncthreads();
     }
 }
 
 template <bool HALO>
 int launch_mfma(const MfmaArgs& a, hipStream_t s) {
     const size_t lds_bytes = 160 * 1024;
+#ifdef SGP_ABLATION
+#define SGP_ABL(V)                                                                                 \
+    if (tiled_variant() == V) {                                                                    \
+        auto k4 = spmm_mfma<HALO, V>;                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(k4, dim3(a.n_tiles * a.n_tchunks, a.feat / 64), dim3(1024), 160 * 1024, s, a); \
+        return sgp::check_launch("spmm_mfma");                                                     \
+    }
+    SGP_ABL(4) SGP_ABL(5) SGP_ABL(6) SGP_ABL(7) SGP_ABL(8) SGP_ABL(9)
+#undef SGP_ABL
+#endif
     auto kern = spmm_mfma<HALO>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -591,18 +662,20 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
 }
 
 int32_t sgp_spmm_mfma_max_union(void) { return kMfmaPasses * 64; }
-int32_t sgp_spmm_mfma_max_chunks(void) { return kMfmaMaxChunks; }
+int32_t sgp_spmm_mfma_max_quads(void) { return kMfmaMaxQuads; }
 
 int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* ucol,
-                      const int32_t* gptr, const int32_t* goff, const float* gw,
-                      int32_t n_tiles, int32_t max_union, int32_t max_tile_chunks,
+                      const int32_t* gptr, const uint16_t* gidx, const float* gw,
+                      const int32_t* rowmap, const int32_t* gsteps,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t xrs, int64_t xbs,
                       const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
                       float* Y, int64_t yrs, int64_t ybs,
                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                       sgp_stream_t stream) {
-    SGP_REQUIRE(trow && uptr && ucol && gptr && goff && gw && X && Y, "sgp_spmm_mfma_f32: null pointer");
-    SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_chunks >= 0,
+    SGP_REQUIRE(trow && uptr && ucol && gptr && gidx && gw && rowmap && gsteps && X && Y,
+                "sgp_spmm_mfma_f32: null pointer");
+    SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,
                 "sgp_spmm_mfma_f32: bad size");
     {
         const long long own = Xh ? n_own : n_cols, far = Xh ? n_cols - n_own : 0;
@@ -612,15 +685,16 @@ int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* u
     if (n_rows == 0 || batch == 0 || feat == 0) return 0;
     if (feat % 64 != 0)
         return sgp::fail(SGP_EUNSUP, "sgp_spmm_mfma_f32: feat=%d is not a multiple of 64", feat);
-    if (max_union > kMfmaPasses * 64 || max_tile_chunks > kMfmaMaxChunks)
-        return sgp::fail(SGP_EUNSUP, "sgp_spmm_mfma_f32: tile working set (%d rows, %d chunks) exceeds LDS (%d, %d)",
-                         max_union, max_tile_chunks, kMfmaPasses * 64, kMfmaMaxChunks);
-    SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && sgp::aligned16(X) &&
-                (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh))) &&
-                sgp::aligned16(goff) && sgp::aligned16(gw),
+    if (max_union > kMfmaPasses * 64 || max_tile_quads > kMfmaMaxQuads)
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_mfma_f32: tile working set (%d rows, %d quads) exceeds LDS (%d, %d)",
+                         max_union, max_tile_quads, kMfmaPasses * 64, kMfmaMaxQuads);
+    SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && yrs % 4 == 0 && ybs % 4 == 0 && sgp::aligned16(X) &&
+                sgp::aligned16(Y) && (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh))) &&
+                sgp::aligned16(gidx) && sgp::aligned16(gw),
                 "sgp_spmm_mfma_f32: strides/pointers must be 16-byte aligned");
     MfmaArgs a;
-    a.trow = trow; a.uptr = uptr; a.ucol = ucol; a.gptr = gptr; a.goff = goff; a.gw = gw;
+    a.trow = trow; a.uptr = uptr; a.ucol = ucol; a.gptr = gptr; a.gidx = gidx; a.gw = gw;
+    a.rowmap = rowmap; a.gsteps = gsteps;
     a.n_tiles = n_tiles;
     a.src = Src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
     a.Y = Y; a.yrs = yrs; a.ybs = ybs;

@@ -216,11 +216,13 @@ class TilePlan:
     n_rows: int
     max_union: int
     max_row_edges: int
-    gptr: Optional[torch.Tensor] = None     # int32 [16 * n_tiles + 1], chunk ranges of the 4-row groups
+    gptr: Optional[torch.Tensor] = None     # int32 [16 * n_tiles + 1], quad ranges of the 4-row groups
     group_fill: float = 0.0                 # useful / issued FMAs of the row-group stream
-    goff: Optional[torch.Tensor] = None     # int32 [n_chunks, 4]
-    gw: Optional[torch.Tensor] = None       # float32 [n_chunks, 4 rows, 4 steps]
-    max_tile_chunks: int = 0
+    gidx: Optional[torch.Tensor] = None     # uint16 (int16 storage) [n_quads, 4 classes, 4]
+    gw: Optional[torch.Tensor] = None       # float32 [n_quads, 4 classes, 4 rows, 4]
+    max_tile_quads: int = 0
+    rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
+    gsteps: Optional[torch.Tensor] = None   # int32 [16 * n_tiles] super-steps per group
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
@@ -228,7 +230,7 @@ class TilePlan:
                         self.erow.to(device), self.ecol.to(device), self.eval.to(device),
                         self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
                         self.max_row_edges, mv(self.gptr), self.group_fill,
-                        mv(self.goff), mv(self.gw), self.max_tile_chunks)
+                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap), mv(self.gsteps))
 
 
 def tile_unions(rowptr, col, trow):
@@ -276,43 +278,95 @@ GROUP_ROWS = 4          # rows per wave in sgp_spmm_mfma_f32
 GROUPS_PER_TILE = 16    # 16 waves per workgroup -> tiles of at most 64 rows
 
 
-def build_group_stream(trow, lcol, row_of_edge, val, row_bytes=256):
-    """Row-group stream of ``sgp_spmm_mfma_f32`` (include/sgp_amd.h): for every group of 4
-    consecutive rows of a tile, the sorted union of the rows' local column indices with the
-    four weights of each column (0 where a row lacks it), 4 steps per chunk."""
+def cluster_rows_in_tiles(trow, uptr, lcol, row_of_edge):
+    """Within every tile, order the rows so that each consecutive 4 ("row group") share as many
+    source columns as possible: a group's column union is what its wave walks, so similar rows
+    mean fewer steps (higher fill) and -- just as important -- groups of similar length, since a
+    workgroup waits for its longest group.  Greedy: seed with the row that overlaps least with
+    the rest (a corner of the tile), then add the 3 rows that overlap most with the group.
+    Returns ``slot_of_row`` (position of every row inside its tile)."""
+    n_tiles = len(trow) - 1
+    n_rows = int(trow[-1])
+    slot_of_row = np.zeros(n_rows, dtype=np.int64)
+    order = np.argsort(row_of_edge, kind="stable")
+    re, le = row_of_edge[order], lcol[order]
+    estart = np.searchsorted(re, np.arange(n_rows + 1))
+    for k in range(n_tiles):
+        r0, r1 = int(trow[k]), int(trow[k + 1])
+        h = r1 - r0
+        if h <= GROUP_ROWS:
+            slot_of_row[r0:r1] = np.arange(h)
+            continue
+        u = int(uptr[k + 1] - uptr[k])
+        m = np.zeros((h, max(u, 1)), dtype=np.float32)
+        e0, e1 = estart[r0], estart[r1]
+        m[re[e0:e1] - r0, le[e0:e1]] = 1.0
+        g = m @ m.T                                           # pairwise overlaps
+        free = np.ones(h, dtype=bool)
+        pos = 0
+        while free.any():
+            idx = np.flatnonzero(free)
+            seed = idx[np.argmin(g[idx][:, idx].sum(1))]
+            members = [seed]
+            free[seed] = False
+            score = g[seed].copy()
+            for _ in range(GROUP_ROWS - 1):
+                if not free.any():
+                    break
+                cand = np.flatnonzero(free)
+                nxt = cand[np.argmax(score[cand])]
+                members.append(nxt)
+                free[nxt] = False
+                score += g[nxt]
+            for mrow in members:
+                slot_of_row[r0 + mrow] = pos
+                pos += 1
+    return slot_of_row
+
+
+def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
+    """Row-group stream of ``sgp_spmm_mfma_f32`` (include/sgp_amd.h).  Slot s of a tile belongs
+    to group s // 4; for every group: the sorted union of its rows' local column indices,
+    dealt round-robin to 4 classes (position p -> super-step p // 4, class p % 4), stored 4
+    super-steps per "quad" as weights ``gw[quad][class][row][4]`` and indices
+    ``gidx[quad][class][4]``."""
     n_tiles = len(trow) - 1
     n_rows = int(trow[-1])
     tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
-    in_tile = np.arange(n_rows, dtype=np.int64) - trow[tile_of_row]
+    in_tile = np.arange(n_rows, dtype=np.int64) - trow[tile_of_row] if slot_of_row is None \
+        else slot_of_row
     assert in_tile.max(initial=0) < GROUP_ROWS * GROUPS_PER_TILE
     group_of_row = tile_of_row * GROUPS_PER_TILE + in_tile // GROUP_ROWS
-    slot_of_row = in_tile % GROUP_ROWS
+    slot_in_group = in_tile % GROUP_ROWS
     n_groups = n_tiles * GROUPS_PER_TILE
     g_e = group_of_row[row_of_edge]
     key = g_e * 65536 + lcol
-    uniq, inv = np.unique(key, return_inverse=True)          # one entry per (group, column) step
+    uniq, inv = np.unique(key, return_inverse=True)          # one entry per (group, column)
     g_s = uniq >> 16
     counts = np.bincount(g_s, minlength=n_groups)
-    chunks = (counts + 3) // 4
+    quads = (counts + 15) // 16                              # 16 columns per quad
     gptr = np.zeros(n_groups + 1, dtype=np.int64)
-    gptr[1:] = np.cumsum(chunks)
+    gptr[1:] = np.cumsum(quads)
     first = np.zeros(n_groups + 1, dtype=np.int64)
     first[1:] = np.cumsum(counts)
-    pos = gptr[g_s] * 4 + (np.arange(uniq.size, dtype=np.int64) - first[g_s])   # padded step index
-    n_steps = int(gptr[-1]) * 4
-    off = np.zeros(n_steps, dtype=np.int32)
-    off[pos] = ((uniq & 0xffff) * row_bytes).astype(np.int32)
-    w = np.zeros((n_steps, GROUP_ROWS), dtype=np.float32)
-    w[pos[inv], slot_of_row[row_of_edge]] = val
-    fill = float(lcol.size) / max(1, n_steps * GROUP_ROWS)
-    # offsets [chunk][step], weights [chunk][row][step]
-    goff = np.ascontiguousarray(off.reshape(-1, 4))
-    gw = np.ascontiguousarray(w.reshape(-1, 4, GROUP_ROWS).transpose(0, 2, 1))
-    return gptr.astype(np.int32), fill, goff, gw
+    p = np.arange(uniq.size, dtype=np.int64) - first[g_s]    # position in the group's union
+    quad = gptr[g_s] + p // 16
+    sup, cls = (p // 4) % 4, p % 4
+    n_quads = int(gptr[-1])
+    gidx = np.zeros((n_quads, 4, 4), dtype=np.uint16)
+    gidx[quad, cls, sup] = (uniq & 0xffff).astype(np.uint16)
+    gw = np.zeros((n_quads, 4, GROUP_ROWS, 4), dtype=np.float32)
+    gw[quad[inv], cls[inv], slot_in_group[row_of_edge], sup[inv]] = val
+    fill = float(lcol.size) / max(1, n_quads * 16 * GROUP_ROWS)
+    # row id stored per (tile, slot); -1 = no row in this slot
+    rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)
+    rowmap[tile_of_row * (GROUP_ROWS * GROUPS_PER_TILE) + in_tile] = np.arange(n_rows, dtype=np.int32)
+    gsteps = ((counts + 3) // 4).astype(np.int32)
+    return gptr.astype(np.int32), fill, gidx, gw, rowmap, gsteps
 
 
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
-                    candidates=(64, 32, 16)) -> Optional[TilePlan]:
+                    candidates=(64, 32, 16), cluster=True) -> Optional[TilePlan]:
     """Tallest tiling whose per-tile working set fits the LDS stage, or None when the
     graph has no locality to exploit (average tile would stage more than it reuses)."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -350,9 +404,13 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                         torch.from_numpy(ecol.view(np.int16)), torch.from_numpy(evalv),
                         int(np.diff(trow).max()), n_tiles, int(n_rows), mu, mre)
         if plan.tile_rows <= GROUP_ROWS * GROUPS_PER_TILE:
-            gptr, fill, goff, gw = build_group_stream(trow, lcol, row_of_edge, np.asarray(val))
+            slots = cluster_rows_in_tiles(trow, uptr, lcol, row_of_edge) if cluster else None
+            gptr, fill, gidx, gw, rowmap, gsteps = build_group_stream(
+                trow, lcol, row_of_edge, np.asarray(val), slots)
+            plan.gsteps = torch.from_numpy(gsteps)
             plan.gptr, plan.group_fill = torch.from_numpy(gptr), fill
-            plan.goff, plan.gw = torch.from_numpy(goff), torch.from_numpy(gw)
-            plan.max_tile_chunks = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
+            plan.gidx, plan.gw = torch.from_numpy(gidx.view(np.int16)), torch.from_numpy(gw)
+            plan.rowmap = torch.from_numpy(rowmap)
+            plan.max_tile_quads = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
         return plan
     return None

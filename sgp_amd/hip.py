@@ -34,14 +34,14 @@ SIGNATURES = {
                                           c_p, c_i64, c_i64, c_i32,
                                           c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p,
+    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                          c_i32, c_i32, c_i32,
                                          c_p, c_i64, c_i64,
                                          c_p, c_i64, c_i64, c_i32,
                                          c_p, c_i64, c_i64,
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_spmm_mfma_max_union": (c_i32, []),
-    "sgp_spmm_mfma_max_chunks": (c_i32, []),
+    "sgp_spmm_mfma_max_quads": (c_i32, []),
     "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
     "sgp_spmm_tiled_max_tile_rows": (c_i32, []),
     "sgp_spmm_tiled_max_row_edges": (c_i32, []),
@@ -192,8 +192,8 @@ def spmm_mfma(plan, x, y, halo=None, n_own=None):
         hp, hrs, hbs, n_own = None, 0, 0, 0
     _check(lib.sgp_spmm_mfma_f32(
         plan.trow.data_ptr(), plan.uptr.data_ptr(), plan.ucol.data_ptr(),
-        plan.gptr.data_ptr(), plan.goff.data_ptr(), plan.gw.data_ptr(),
-        plan.n_tiles, plan.max_union, plan.max_tile_chunks,
+        plan.gptr.data_ptr(), plan.gidx.data_ptr(), plan.gw.data_ptr(), plan.rowmap.data_ptr(),
+        plan.gsteps.data_ptr(), plan.n_tiles, plan.max_union, plan.max_tile_quads,
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mfma_f32")

@@ -192,10 +192,9 @@ def main():
             per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
             bts = hop_bytes(N, T, d_h, nnz)
             achieved = bts / (per_launch * 1e-3) / 1e9
-            plan = ops[0].tile_plan(d_h, dev)
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": "spmm_tiled" if plan is not None else "spmm_csr_rows",
+                               "kernel": getattr(ops[0], "last_kernel", "?"),
                                "ms_per_launch": per_launch, "algorithmic_bytes": bts}
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(w)

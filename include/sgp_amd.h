@@ -107,7 +107,6 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
  *   gw  [quad][q][row i][4]   float   weight of row i for class q's column in super-steps 0..3
  *                                     of the quad (0 = row lacks the column / padding)
  *   gidx[quad][q][4]          uint16  index of that column in the tile's ucol list (0 = padding)
- *   gsteps[k * 16 + g]        int32   super-steps of the group (= ceil(columns / 4) <= 4 * quads)
  *   rowmap[64 * k + 4 g + i]  int32   output row of slot i of group g of tile k, -1 = empty
  *                                     (the host may permute rows inside a tile so that the 4
  *                                     rows of a group share most of their columns)
@@ -115,7 +114,7 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
  * tile (weights and indices are LDS-resident). */
 int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
                       const int32_t* gptr, const uint16_t* gidx, const float* gw,
-                      const int32_t* rowmap, const int32_t* gsteps,
+                      const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                       const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,

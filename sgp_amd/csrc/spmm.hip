@@ -318,7 +318,6 @@ int tiled_variant();
 struct MfmaArgs {
     const int* trow; const int* uptr; const int* ucol;
     const int* gptr; const unsigned short* gidx; const float* gw; const int* rowmap;
-    const int* gsteps;
     int n_tiles;
     Src src;
     float* Y; long long yrs, ybs;
@@ -385,12 +384,12 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
         for (int i = tid; i < tile_quads * 2; i += 1024) idst[i] = isrc[i];
     }
 
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: branches stay uniform
     const int lane = tid & 63;
     const int q = lane >> 4;
     const int grp = tile * 16 + wave;
-    const int q_begin = a.gptr[grp] - tile_q0, n_quads = a.gptr[grp + 1] - a.gptr[grp];
-    const int n_super = a.gsteps[grp];                     // super-steps actually used
+    const int q_begin = __builtin_amdgcn_readfirstlane(a.gptr[grp]) - tile_q0;
+    const int n_quads = __builtin_amdgcn_readfirstlane(a.gptr[grp + 1]) - (q_begin + tile_q0);
     const int my_row = a.rowmap[tile * 64 + wave * 4 + q];   // output row of class q (-1: none)
     const char* wmine = wlds + q_begin * 256 + (q * 4 + (lane & 3)) * 16;
     const char* imine = ilds + q_begin * 32 + q * 8;
@@ -450,11 +449,11 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
                 wn = *reinterpret_cast<const f32x4*>(wmine + ((C) + 1) * 256);                  \
                 in = *reinterpret_cast<const uint2*>(imine + ((C) + 1) * 32);                   \
             }                                                                                   \
-            const int left = n_super - 4 * (C);        /* super-steps left (wave-uniform) */    \
+            /* padded super-steps carry zero weights: no branch, the MFMA adds 0 */             \
             SGP_SUPER(wv.x, ix.x & 0xffffu)                                                     \
-            if (left > 1) SGP_SUPER(wv.y, ix.x >> 16)                                           \
-            if (left > 2) SGP_SUPER(wv.z, ix.y & 0xffffu)                                       \
-            if (left > 3) SGP_SUPER(wv.w, ix.y >> 16)                                           \
+            SGP_SUPER(wv.y, ix.x >> 16)                                                         \
+            SGP_SUPER(wv.z, ix.y & 0xffffu)                                                     \
+            SGP_SUPER(wv.w, ix.y >> 16)                                                         \
         }
         // first PASSES quads carry one prefetch load each; the rest run in a plain loop
         if constexpr (ABL != 8 && ABL != 9) {
@@ -666,14 +665,14 @@ int32_t sgp_spmm_mfma_max_quads(void) { return kMfmaMaxQuads; }
 
 int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* ucol,
                       const int32_t* gptr, const uint16_t* gidx, const float* gw,
-                      const int32_t* rowmap, const int32_t* gsteps,
+                      const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t xrs, int64_t xbs,
                       const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
                       float* Y, int64_t yrs, int64_t ybs,
                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                       sgp_stream_t stream) {
-    SGP_REQUIRE(trow && uptr && ucol && gptr && gidx && gw && rowmap && gsteps && X && Y,
+    SGP_REQUIRE(trow && uptr && ucol && gptr && gidx && gw && rowmap && X && Y,
                 "sgp_spmm_mfma_f32: null pointer");
     SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,
                 "sgp_spmm_mfma_f32: bad size");
@@ -694,7 +693,7 @@ int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* u
                 "sgp_spmm_mfma_f32: strides/pointers must be 16-byte aligned");
     MfmaArgs a;
     a.trow = trow; a.uptr = uptr; a.ucol = ucol; a.gptr = gptr; a.gidx = gidx; a.gw = gw;
-    a.rowmap = rowmap; a.gsteps = gsteps;
+    a.rowmap = rowmap;
     a.n_tiles = n_tiles;
     a.src = Src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
     a.Y = Y; a.yrs = yrs; a.ybs = ybs;

@@ -170,9 +170,15 @@ class ShiftOperator:
             plan = None                      # tiled kernels use 32-bit row offsets
         if force in ("tiled", "mfma") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
-        if plan is not None and force == "mfma":
-            if plan.gw is None:
-                raise NotImplementedError("no row-group stream for this plan")
+        if force == "mfma" and (plan is None or plan.gw is None):
+            raise NotImplementedError("no row-group stream for this plan")
+        # matrix-core row groups pay off when 4-row groups share most columns (k-NN graphs)
+        use_mfma = plan is not None and plan.gw is not None and \
+            (force == "mfma" or (force is None and plan.group_fill >= 0.5 and
+                                 plan.max_tile_quads <= hip.load().sgp_spmm_mfma_max_quads()))
+        self.last_kernel = "spmm_mfma" if use_mfma else ("spmm_tiled" if plan is not None
+                                                         else "spmm_csr_rows")
+        if use_mfma:
             hip.spmm_mfma(plan, x, y, halo, self.num_nodes)
         elif plan is not None:
             hip.spmm_tiled(plan, x, y, halo, self.num_nodes)
@@ -222,7 +228,6 @@ class TilePlan:
     gw: Optional[torch.Tensor] = None       # float32 [n_quads, 4 classes, 4 rows, 4]
     max_tile_quads: int = 0
     rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
-    gsteps: Optional[torch.Tensor] = None   # int32 [16 * n_tiles] super-steps per group
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
@@ -230,7 +235,7 @@ class TilePlan:
                         self.erow.to(device), self.ecol.to(device), self.eval.to(device),
                         self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
                         self.max_row_edges, mv(self.gptr), self.group_fill,
-                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap), mv(self.gsteps))
+                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap))
 
 
 def tile_unions(rowptr, col, trow):
@@ -361,8 +366,7 @@ def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
     # row id stored per (tile, slot); -1 = no row in this slot
     rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)
     rowmap[tile_of_row * (GROUP_ROWS * GROUPS_PER_TILE) + in_tile] = np.arange(n_rows, dtype=np.int32)
-    gsteps = ((counts + 3) // 4).astype(np.int32)
-    return gptr.astype(np.int32), fill, gidx, gw, rowmap, gsteps
+    return gptr.astype(np.int32), fill, gidx, gw, rowmap
 
 
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
@@ -405,9 +409,8 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                         int(np.diff(trow).max()), n_tiles, int(n_rows), mu, mre)
         if plan.tile_rows <= GROUP_ROWS * GROUPS_PER_TILE:
             slots = cluster_rows_in_tiles(trow, uptr, lcol, row_of_edge) if cluster else None
-            gptr, fill, gidx, gw, rowmap, gsteps = build_group_stream(
+            gptr, fill, gidx, gw, rowmap = build_group_stream(
                 trow, lcol, row_of_edge, np.asarray(val), slots)
-            plan.gsteps = torch.from_numpy(gsteps)
             plan.gptr, plan.group_fill = torch.from_numpy(gptr), fill
             plan.gidx, plan.gw = torch.from_numpy(gidx.view(np.int16)), torch.from_numpy(gw)
             plan.rowmap = torch.from_numpy(rowmap)

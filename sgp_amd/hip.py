@@ -34,7 +34,7 @@ SIGNATURES = {
                                           c_p, c_i64, c_i64, c_i32,
                                           c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                          c_i32, c_i32, c_i32,
                                          c_p, c_i64, c_i64,
                                          c_p, c_i64, c_i64, c_i32,
@@ -193,7 +193,7 @@ def spmm_mfma(plan, x, y, halo=None, n_own=None):
     _check(lib.sgp_spmm_mfma_f32(
         plan.trow.data_ptr(), plan.uptr.data_ptr(), plan.ucol.data_ptr(),
         plan.gptr.data_ptr(), plan.gidx.data_ptr(), plan.gw.data_ptr(), plan.rowmap.data_ptr(),
-        plan.gsteps.data_ptr(), plan.n_tiles, plan.max_union, plan.max_tile_quads,
+        plan.n_tiles, plan.max_union, plan.max_tile_quads,
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mfma_f32")

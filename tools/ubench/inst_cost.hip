@@ -16,7 +16,7 @@ __global__ void bench(unsigned long long* out, float* sink, int iters, float sva
     float a0 = lane, a1 = 1, a2 = 2, a3 = 3, a4 = 4, a5 = 5, a6 = 6, a7 = 7;
     float x = lane * 0.5f, w = 0.25f;
     int ad = lane * 4, ad16 = lane * 16, ad8 = lane * 8;
-    f32x4 m = {0, 0, 0, 0};
+    f32x4 m = {0, 0, 0, 0}, m2 = {0, 0, 0, 0};
     f32x4 r0, r1, r2, r3;
     double d0 = lane, d1 = 1, d2 = 2, d3 = 3, dm = 0.5, dn = 0.25;
     float q0, q1, q2, q3;
@@ -87,6 +87,22 @@ __global__ void bench(unsigned long long* out, float* sink, int iters, float sva
                                "v_fmac_f32_dpp %11, %13, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %12, %13, %14 row_ror:1 row_mask:0xf bank_mask:0xf\n s_waitcnt lgkmcnt(0)"
                                : "=v"(r0), "=v"(r1), "=v"(r2), "=v"(r3) : "v"(ad16),
                                  "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(a4), "v"(a5), "v"(a6), "v"(a7), "v"(w), "v"(x));)
+        } else if constexpr (KIND == 15 || KIND == 16) {  // 4 b128 -> 16 mfma on the loaded data
+            // KIND 15: read, wait, compute.  KIND 16: the next iteration's reads are issued first.
+            for (int u = 0; u < 16; ++u) {
+                int o = (it * 16 + u) & 7;
+                asm volatile("" : "+v"(o));
+                const char* base = lds + ad16 + o * 4096;
+                f32x4 n0 = *(const f32x4*)(base), n1 = *(const f32x4*)(base + 1024);
+                f32x4 n2 = *(const f32x4*)(base + 2048), n3 = *(const f32x4*)(base + 3072);
+                f32x4 c0 = n0, c1 = n1, c2 = n2, c3 = n3;
+                if constexpr (KIND == 16) { c0 = r0; c1 = r1; c2 = r2; c3 = r3; }
+#define M4(XV) m = __builtin_amdgcn_mfma_f32_4x4x1f32(w, XV.x, m, 0, 0, 0); m2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w, XV.y, m2, 0, 0, 0); \
+               m = __builtin_amdgcn_mfma_f32_4x4x1f32(w, XV.z, m, 0, 0, 0); m2 = __builtin_amdgcn_mfma_f32_4x4x1f32(w, XV.w, m2, 0, 0, 0);
+                M4(c0) M4(c1) M4(c2) M4(c3)
+#undef M4
+                if constexpr (KIND == 16) { r0 = n0; r1 = n1; r2 = n2; r3 = n3; }
+            }
         } else if constexpr (KIND == 13) {  // ds_read_b32 broadcast (all lanes same address) x8
             REP16(asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:256\n ds_read_b32 %2, %8 offset:512\n ds_read_b32 %3, %8 offset:768\n"
                                "ds_read_b32 %4, %8 offset:1024\n ds_read_b32 %5, %8 offset:1280\n ds_read_b32 %6, %8 offset:1536\n ds_read_b32 %7, %8 offset:1792\n s_waitcnt lgkmcnt(0)"
@@ -98,7 +114,7 @@ __global__ void bench(unsigned long long* out, float* sink, int iters, float sva
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
-    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + r0.x + r1.y + r2.z + r3.w + m.x + (float)(d0 + d1 + d2 + d3);
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + r0.x + r1.y + r2.z + r3.w + m.x + m2.y + (float)(d0 + d1 + d2 + d3);
     unsigned long long w1 = wall_clock64();
     if (threadIdx.x == 0) { out[2 * blockIdx.x] = t1 - t0; out[2 * blockIdx.x + 1] = w1 - w0; }
     (void)q0; (void)q1; (void)q2; (void)q3;
@@ -141,6 +157,8 @@ int main() {
         run<10>("v_readlane", 8, thr, 256);
         run<11>("2 b128 + 8 fmac", 10, thr, 256);
         run<12>("2 b128 + 8 fmac_dpp", 10, thr, 256);
+        run<15>("4 b128 -> 16 mfma (dep)", 20, thr, 256);
+        run<16>("4 b128 -> 16 mfma (pipelined)", 20, thr, 256);
         run<13>("ds_read_b32 bcast", 8, thr, 256);
         run<14>("ds_read_b128 4-row bcast", 8, thr, 256);
     }

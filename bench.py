@@ -34,7 +34,7 @@ WORKLOADS = {
     "target": dict(N=100000, T=1024, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
     "c3": dict(N=10000, T=2016, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
     "c2": dict(N=325, T=52116, F=3, R=128, L=1, K=4, bidir=True, glob=True, graph="traffic"),
-    "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=False, glob=False, graph="knn100"),
+    "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=True, glob=True, graph="knn100"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 
@@ -93,14 +93,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
+    if args.gpus > 1 and world != args.gpus and "SGP_BENCH_BACKEND" not in os.environ:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with "
                          f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})")
     hip.require_gpu()
+    # SGP_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the
+    # partitioned path on a 1-GPU box); the measured configuration is nccl = RCCL, one GPU each.
+    backend = os.environ.get("SGP_BENCH_BACKEND", "nccl")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
     N, T, F, R, L, K = w["N"], w["T"], w["F"], w["R"], w["L"], w["K"]
@@ -122,8 +126,13 @@ def main():
         spatial, lo, hi = None, 0, N
         local_ops = ops
     n_own = hi - lo
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x = torch.randn(T, n_own, F, device=dev, generator=g)   # synthetic, resident in HBM
+    dump = os.environ.get("SGP_BENCH_DUMP")                # tests: same input on every layout
+    if dump:
+        g = torch.Generator(device=dev).manual_seed(1234)
+        x = torch.randn(T, N, F, device=dev, generator=g)[:, lo:hi].contiguous()
+    else:
+        g = torch.Generator(device=dev).manual_seed(1234 + rank)
+        x = torch.randn(T, n_own, F, device=dev, generator=g)   # synthetic, resident in HBM
     out = torch.empty(T, n_own, enc.output_size, device=dev)
     for o in local_ops:                                     # plans + device CSR built once
         o.tile_plan(d_h, dev)
@@ -168,10 +177,13 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], dtype=torch.float64,
+                          device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    if dump:
+        torch.save(out.cpu(), os.path.join(dump, f"out_w{world}_r{rank}.pt"))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = N * T * args.steps / elapsed

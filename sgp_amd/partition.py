@@ -138,8 +138,15 @@ class HaloExchange:
         send, recv = self._buffers(T, D, x.device)
         if send.shape[0]:
             self.ops.gather_nodes(x, self._idx, send.permute(1, 0, 2))
-        dist.all_to_all_single(recv, send, output_split_sizes=self.block.recv_counts,
-                               input_split_sizes=self.block.send_counts, group=self.group)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":
+            # test rigs only (several ranks sharing one GPU): gloo has no device all_to_all
+            r_cpu = torch.empty(recv.shape, dtype=recv.dtype)
+            dist.all_to_all_single(r_cpu, send.cpu(), output_split_sizes=self.block.recv_counts,
+                                   input_split_sizes=self.block.send_counts, group=self.group)
+            recv.copy_(r_cpu)
+        else:
+            dist.all_to_all_single(recv, send, output_split_sizes=self.block.recv_counts,
+                                   input_split_sizes=self.block.send_counts, group=self.group)
         return recv.permute(1, 0, 2)
 
 
@@ -172,7 +179,12 @@ class PartitionedSpatial:
             p = self.num_blocks() - 1
             sums = self.ops.node_sums(out[:, :, :feat])
             if self.world_size > 1:
-                dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
+                if sums.is_cuda and dist.get_backend(self.group) == "gloo":
+                    s_cpu = sums.cpu()
+                    dist.all_reduce(s_cpu, op=dist.ReduceOp.SUM, group=self.group)
+                    sums.copy_(s_cpu)
+                else:
+                    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=self.group)
             self.ops.bcast_rows(sums, 1.0 / self.n_total, out[:, :, p * feat:(p + 1) * feat])
         return out
 

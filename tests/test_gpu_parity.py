@@ -351,3 +351,26 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
             close(y, ref[:, blk.lo:blk.hi])
         with pytest.raises(ValueError):
             blk.op.propagate(xo, y)
+
+
+def test_bench_two_ranks_share_one_gpu_matches_single_rank(tmp_path):
+    """bench.py's node-partitioned path end to end (gather kernel, halo SpMM kernels, exchange,
+    global mean) with 2 ranks on this one GPU over gloo == the single-rank result."""
+    import subprocess, sys, json
+    from conftest import ROOT
+    env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_DUMP=str(tmp_path))
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                          "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                          str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--workload", "small", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    rec = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    full = torch.load(tmp_path / "out_w1_r0.pt")
+    parts = [torch.load(tmp_path / f"out_w2_r{r}.pt") for r in range(2)]
+    close(torch.cat(parts, 1), full, rtol=1e-6, atol=1e-6)

@@ -224,6 +224,156 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
 
 constexpr int kLdsLimit = 160 * 1024;
 
+// ---- small-N variant: one node tile per workgroup, the j-tiles split over its 4 waves -------
+// With a few hundred nodes (METR-LA 207, PEMS-BAY 325) there are only a dozen node tiles, and a
+// single wave stepping all JT output tiles is a serial chain of JT*(4*JT+NKX) MFMAs per time
+// step.  Here the 4 waves of a workgroup (one per SIMD) each compute JT/4 of the output tiles
+// for the SAME 16 nodes, then exchange the new state through a double-buffered LDS slab (the
+// C-layout tile of a wave is written as-is: it is already the B-operand layout every wave
+// needs), one barrier per step.
+template <int JT, int NKX>
+__global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
+    static_assert(JT % 4 == 0, "split-J needs at least one j-tile per wave");
+    constexpr int JW = JT / 4;                           // j-tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    {
+        const int total4 = (int)(packed_floats(JT, NKX) / 4);
+        for (int i = threadIdx.x; i < total4; i += 256)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wp)[i];
+    }
+    const float* bias = lds;
+    const float* wx = lds + JT * 16;
+    const float* wh = wx + JT * NKX * 64;
+    f32x4* hbuf = reinterpret_cast<f32x4*>(lds + packed_floats(JT, NKX));   // [2][JT][64] f32x4
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_in = lane & 15, q = lane >> 4;
+    const int node = blockIdx.x * 16 + n_in;
+    const bool ok = node < a.N;
+
+    f32x4 h[JT];                                         // full state as B operands
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        h[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.h_state && ok) {
+            const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + r < a.R) h[jt][r] = a.h_state[(long long)node * a.R + j0 + r];
+        }
+    }
+    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+    __syncthreads();
+
+    for (int t = 0; t < a.T; ++t) {
+        int wo = 0;
+        asm volatile("" : "+v"(wo));                     // keep the fragments in LDS (see above)
+        const float* bias_t = bias + wo;
+        const float* wx_t = wx + wo;
+        const float* wh_t = wh + wo;
+        float xr[NKX];
+        {
+            const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks)
+                xr[ks] = (ok && q * NKX + ks < a.F) ? xp[ks] : 0.f;
+        }
+        f32x4 acc[JW];
+#pragma unroll
+        for (int w = 0; w < JW; ++w)
+            acc[w] = *reinterpret_cast<const f32x4*>(bias_t + (wave * JW + w) * 16 + q * 4);
+#pragma unroll
+        for (int kb = 0; kb < JT; ++kb) {
+            f32x4 wf[JW];
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+                wf[w] = *reinterpret_cast<const f32x4*>(wh_t + (((wave * JW + w) * JT + kb) * 64 + lane) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int w = 0; w < JW; ++w)
+                    acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[w][s], h[kb][s], acc[w], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks)
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+                acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[((wave * JW + w) * NKX + ks) * 64 + lane],
+                                                               xr[ks], acc[w], 0, 0, 0);
+        if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[w][r] = tanh_f32(acc[w][r]);
+        } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[w][r] = fmaxf(acc[w][r], 0.f);
+        }
+        f32x4* hb = hbuf + (t & 1) * JT * 64;
+        if (a.act == SGP_ACT_SELF_NORM) {
+            // norm over all R features: partial sums of the 4 waves meet in LDS
+            float ss = 0.f;
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss = fmaf(acc[w][r], acc[w][r], ss);
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            float* red = reinterpret_cast<float*>(hbuf + 2 * JT * 64) + (t & 1) * 64;
+            if (q == 0) red[wave * 16 + n_in] = ss;
+            __syncthreads();
+            const float tot = red[n_in] + red[16 + n_in] + red[32 + n_in] + red[48 + n_in];
+            const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[w][r] *= inv;
+        }
+        // leak, publish my tiles, store them
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            const int jt = wave * JW + w;
+            f32x4 hn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                hn[r] = a.one_minus_alpha * h[jt][r] + a.alpha * acc[w][r];
+            hb[jt * 64 + lane] = hn;
+            const int j0 = 16 * jt + 4 * q;
+            if (ok && j0 < a.R) {
+                float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
+                if (o_vec) {
+                    *reinterpret_cast<f32x4*>(op) = hn;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + r < a.R) op[r] = hn[r];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) h[jt] = hb[jt * 64 + lane];
+    }
+    if (a.h_state && wave == 0) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ok && j0 + r < a.R) a.h_state[(long long)node * a.R + j0 + r] = h[jt][r];
+        }
+    }
+}
+
+template <int JT, int NKX>
+constexpr long long splitj_lds_bytes() {
+    return packed_floats(JT, NKX) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4;
+}
+
 template <int JT, int NKX, int NT>
 int launch_layer(ResArgs a, hipStream_t s) {
     const long long wbytes = packed_floats(JT, NKX) * 4;
@@ -253,6 +403,19 @@ int launch_layer(ResArgs a, hipStream_t s) {
 template <int JT, int NKX>
 int launch_nt(const ResArgs& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
+    if constexpr (JT % 4 == 0 && splitj_lds_bytes<JT, NKX>() <= kLdsLimit) {
+        if (n_tiles <= 512) {                       // up to 2 workgroups per CU: latency-bound regime
+            ResArgs b = a;
+            b.n_tiles = n_tiles;
+            auto kern = reservoir_layer_splitj<JT, NKX>;
+            const int bytes = (int)splitj_lds_bytes<JT, NKX>();
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), (size_t)bytes, s, b);
+            return sgp::check_launch("reservoir_layer_splitj");
+        }
+    }
     if constexpr (JT <= 4) {
         if (n_tiles > 4096) return launch_layer<JT, NKX, 2>(a, s);
     }

@@ -37,6 +37,10 @@ WORKLOADS = {
     "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=True, glob=True, graph="knn100"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+# Fabric-side bytes of one hop launch from rocprofv3 PMC passes of this very command
+# (profiles/r1/bench_target_summary.txt): WRITE_SIZE 2.56e7 KB + 2 x FETCH_SIZE 4.39e7 KB -- on
+# gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM).
+PROFILED_TRAFFIC = {"target": 2.56e7 * 1024 + 2 * 4.39e7 * 1024}
 
 
 def build_graph(w):
@@ -205,7 +209,8 @@ def main():
             bts = hop_bytes(N, T, d_h, nnz)
             achieved = bts / (per_launch * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                               "traffic": PROFILED_TRAFFIC.get(args.workload),
                                "kernel": getattr(ops[0], "last_kernel", "?"),
                                "ms_per_launch": per_launch, "algorithmic_bytes": bts}
         if not args.no_cpu_baseline and world == 1:

@@ -63,6 +63,39 @@ class SGPEncoder(nn.Module):
         self.sgp_encoder.encode_into(out, d_h, ops)
         return out
 
+    # Device-memory budget for one pass (bytes); None = 80 % of what is free right now.  Host
+    # inputs whose input + embedding exceed it are encoded in time chunks (see encode_streamed).
+    max_device_bytes = None
+
+    def _budget(self):
+        if self.max_device_bytes is not None:
+            return int(self.max_device_bytes)
+        free, _ = torch.cuda.mem_get_info()
+        return int(0.8 * free)
+
+    def encode_streamed(self, x, ops, t_chunk):
+        """Host tensor x[T, N, F] -> host tensor [T, N, D_out], ``t_chunk`` steps at a time.
+        The recurrence is carried across chunks in a device-resident state ``[L, N, R]``
+        (``sgp_reservoir_f32``'s h_state); the propagation is independent per time step, so
+        the result is bit-identical to a single pass.  This is how embeddings larger than the
+        288 GB of HBM (BASELINE config C5: 629 GB) or than the free memory are produced."""
+        hip.require_gpu()
+        T, N, _ = x.shape
+        dev = torch.device("cuda", torch.cuda.current_device())
+        L, R = len(self.reservoir.reservoir_layers), self.reservoir.hidden_size
+        d_h = L * R
+        state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
+        out = torch.empty(T, N, self.output_size, dtype=torch.float32)
+        buf = torch.empty(min(t_chunk, T), N, self.output_size, dtype=torch.float32, device=dev)
+        for t0 in range(0, T, t_chunk):
+            t1 = min(T, t0 + t_chunk)
+            xc = x[t0:t1].to(dev, torch.float32, non_blocking=True).contiguous()
+            oc = buf[:t1 - t0]
+            self.reservoir.encode_into(xc, oc[:, :, :d_h], state)
+            self.sgp_encoder.encode_into(oc, d_h, ops)
+            out[t0:t1].copy_(oc)
+        return out
+
     def forward(self, x, edge_index, edge_weight):
         # x : [t n f]
         dev = x.device
@@ -70,6 +103,12 @@ class SGPEncoder(nn.Module):
         xg = x.float()
         if not xg.is_cuda:
             hip.require_gpu()
+            T, N, F = xg.shape
+            per_step = N * (F + self.output_size) * 4
+            budget = self._budget()
+            if T * per_step > budget:
+                t_chunk = max(1, budget // per_step)
+                return self.encode_streamed(xg, ops, t_chunk)
             xg = xg.cuda()
         if xg.stride(2) != 1:
             xg = xg.contiguous()

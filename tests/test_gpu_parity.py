@@ -374,3 +374,18 @@ def test_bench_two_ranks_share_one_gpu_matches_single_rank(tmp_path):
     full = torch.load(tmp_path / "out_w1_r0.pt")
     parts = [torch.load(tmp_path / f"out_w2_r{r}.pt") for r in range(2)]
     close(torch.cat(parts, 1), full, rtol=1e-6, atol=1e-6)
+
+
+def test_streamed_encoding_equals_single_pass():
+    """Time-chunked encoding (embeddings larger than device memory) is bit-identical."""
+    torch.manual_seed(11)
+    n, t = 300, 100
+    ei, ew, _ = synthetic.knn_graph(n, 10, seed=5)
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=32, reservoir_layers=2, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=2,
+                             bidirectional=True, alpha_decay=True, global_attr=True)
+    x = torch.randn(t, n, 3)
+    full = enc(x, ei, ew)
+    enc.max_device_bytes = 7 * n * (3 + enc.output_size) * 4       # forces 7-step chunks
+    chunked = enc(x, ei, ew)
+    assert not chunked.is_cuda and torch.equal(chunked, full)

@@ -295,6 +295,7 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
 }
 
 int tiled_variant();
+int chunk_cap();
 
 // ---------------------------------------------------------------- MFMA row-group kernel
 // Same tile staging as spmm_tiled, different inner product: a wave owns FOUR consecutive output
@@ -521,6 +522,12 @@ constexpr int kTiledPasses = 8;
 constexpr int kTiledCapacity = kTiledPasses * kTiledThreads / 16;   // staged rows per tile
 constexpr int kTiledGroups = kTiledThreads / 16;                    // rows in flight per workgroup
 
+int chunk_cap() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGP_SPMM_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }
+    return v;
+}
+
 int tiled_variant() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("SGP_SPMM_VARIANT"); v = e ? atoi(e) : 1; }
@@ -650,7 +657,7 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
     // far apart in t -- with 431-step chunks rocprofv3 showed 2.4x the algorithmic HBM reads.
     const int nft = feat / 64;
     long long want = (long long)batch * n_tiles * nft / 4096;
-    int tc = (int)(want < 16 ? 16 : (want > 48 ? 48 : want));
+    int tc = (int)(want < 16 ? 16 : (want > chunk_cap() ? chunk_cap() : want));
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
@@ -703,7 +710,7 @@ int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* u
     // far apart in t -- with 431-step chunks rocprofv3 showed 2.4x the algorithmic HBM reads.
     const int nft = feat / 64;
     long long want = (long long)batch * n_tiles * nft / 4096;
-    int tc = (int)(want < 16 ? 16 : (want > 48 ? 48 : want));
+    int tc = (int)(want < 16 ? 16 : (want > chunk_cap() ? chunk_cap() : want));
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;

@@ -32,6 +32,9 @@ from sgp_amd.sgp_preprocessing import spatial_operators  # noqa: E402
 WORKLOADS = {
     # name: N, T, F_in, R, L, K, bidirectional, global_attr, graph
     "target": dict(N=100000, T=1024, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
+    # BASELINE.json configs[0] / [3] shapes (real data files are not available; synthetic graphs)
+    "c1": dict(N=207, T=34272, F=3, R=64, L=1, K=2, bidir=False, glob=False, graph="traffic"),
+    "c4": dict(N=5016, T=8868, F=3, R=16, L=8, K=2, bidir=False, glob=True, graph="knn100"),
     "c3": dict(N=10000, T=2016, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
     "c2": dict(N=325, T=52116, F=3, R=128, L=1, K=4, bidir=True, glob=True, graph="traffic"),
     "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=True, glob=True, graph="knn100"),
@@ -47,7 +50,7 @@ def build_graph(w):
     if w["graph"] == "knn100":
         ei, ew, _ = synthetic.knn_graph(w["N"], 100, seed=1)
     else:
-        ei, ew = synthetic.sparse_traffic_graph(w["N"], 2369, seed=1)
+        ei, ew = synthetic.sparse_traffic_graph(w["N"], 1515 if w["N"] < 300 else 2369, seed=1)
     return ei, ew
 
 
@@ -120,7 +123,7 @@ def main():
     enc = sgp_amd.SGPEncoder(input_size=F, reservoir_size=R, reservoir_layers=L,
                              leaking_rate=0.9, spectral_radius=0.9, density=0.7,
                              input_scaling=1., receptive_field=K, bidirectional=w["bidir"],
-                             alpha_decay=False, global_attr=w["glob"])
+                             alpha_decay=L > 1, global_attr=w["glob"])
     d_h = enc.reservoir.output_size
     if world > 1:
         spatial, bounds = partition.make_partitioned_spatial(ops, K, w["glob"])

@@ -191,6 +191,27 @@ def main():
     save("g4_seed_gesn", seed=np.int64(5), rng_after=torch.rand(4).numpy(),
          **layer_dump(ges))
 
+    # ---- G6: sgp_spatial_support (explicit supports, incl. its quirks) --
+    n6, e6 = 30, 140
+    ei6, ew6 = graph(n6, e6, seed=21)
+    cases = {
+        "plain_k1": dict(k=1), "plain_k3": dict(k=3),
+        "selfloops_k2": dict(k=2, add_self_loops=True),
+        "removeloops_k2": dict(k=2, remove_self_loops=True),
+        "undirected_k2": dict(k=2, undirected=True),
+        "bidir_k2": dict(k=2, bidirectional=True),
+        "bidir_global_k3": dict(k=3, bidirectional=True, global_attr=True),
+        "noweight_k2": dict(k=2),
+    }
+    for name, kw in cases.items():
+        w6 = None if name.startswith("noweight") else ew6
+        sup = ref.sgp_spatial_support(ei6, w6, num_nodes=n6, **kw)
+        dense = [s_.numpy() if torch.is_tensor(s_) else s_.to_dense().numpy() for s_ in sup]
+        save(f"g6_support_{name}", edge_index=ei6.numpy(),
+             edge_weight=(ew6.numpy() if w6 is not None else np.zeros(0, np.float32)),
+             has_weight=np.bool_(w6 is not None), supports=np.stack(dense).astype(np.float32),
+             n=np.int64(n6), **{k_: np.array(v_) for k_, v_ in kw.items()})
+
     # ---- G5: encode_dataset harness -----------------------------------
     class FakeDataset:
         def __init__(self, data, u, ei, ew):

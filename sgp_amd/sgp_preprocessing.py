@@ -129,14 +129,69 @@ def sgp_spatial_embedding(x,
     return res
 
 
+def _row_normalise(a, gcn_norm):
+    import scipy.sparse as sp
+    deg = np.asarray(a.sum(1)).ravel().astype(np.float32)
+    with np.errstate(divide="ignore"):
+        d = np.power(deg, -0.5 if gcn_norm else -1.0)
+    d[np.isinf(d)] = 0
+    out = sp.diags(d) @ a
+    if gcn_norm:
+        out = out @ sp.diags(d)
+    return out.tocsr()
+
+
+def _operator_from_scipy(m):
+    m = m.tocsr()
+    m.sum_duplicates()
+    m.sort_indices()
+    return ShiftOperator(torch.from_numpy(m.indptr.astype(np.int64)),
+                         torch.from_numpy(m.indices.astype(np.int64)),
+                         torch.from_numpy(m.data.astype(np.float32)), m.shape[0])
+
+
 def sgp_spatial_support(edge_index, edge_weight=None, num_nodes=None, k=2, undirected=False,
                         add_self_loops=False, remove_self_loops=False, bidirectional=False,
                         global_attr=False):
-    """lib/sgp_preprocessing.py:108-160 (explicit sparse supports for on-the-fly
-    propagation, ``sgp_preprocessing: True``; no shipped config enables it).  SURVEY.md
-    8f row f3 -- not built yet."""
-    raise NotImplementedError("sgp_spatial_support (on-the-fly supports) is a later row "
-                              "of the scope table; use sgp_spatial_embedding")
+    """lib/sgp_preprocessing.py:108-160: explicit sparse supports for on-the-fly propagation
+    (``sgp_preprocessing: True``).  One-off graph preparation, done on the host with scipy
+    (SpSpGEMM); every support is a :class:`ShiftOperator` whose ``@`` runs on the GPU.  The
+    reference's quirks are kept so that a decoder trained against them sees the same inputs:
+    every support after the first is ``A_hat @ A_hat`` (:143-145), and the ``bidirectional``
+    recursion is handed the un-transposed adjacency (:147-154), i.e. its supports are the
+    row-normalised forward operator again.  ``global_attr`` appends a dense 1/N matrix."""
+    import scipy.sparse as sp
+    if _is_sparse_like(edge_index):
+        row, col, val = edge_index.coo()
+        n = edge_index.size(0)
+        val = np.ones(row.numel(), np.float32) if val is None else val.float().numpy()
+        adj = sp.csr_matrix((val, (row.numpy(), col.numpy())), shape=(n, n))
+    elif sp.issparse(edge_index):
+        adj = edge_index.tocsr().astype(np.float32)
+        n = adj.shape[0]
+    else:
+        ei = torch.as_tensor(edge_index).long().cpu().numpy()
+        n = int(num_nodes) if num_nodes is not None else int(ei.max()) + 1
+        w = np.ones(ei.shape[1], np.float32) if edge_weight is None else \
+            torch.as_tensor(edge_weight).float().cpu().numpy()
+        adj = sp.csr_matrix((w, (ei[1], ei[0])), shape=(n, n))       # "transpose", :117-119
+    adj.sum_duplicates()
+    if undirected:
+        adj = (adj + adj.T).tocsr()
+    if add_self_loops:
+        adj = adj.tolil(); adj.setdiag(1.0); adj = adj.tocsr()
+    elif remove_self_loops:
+        adj = adj.tolil(); adj.setdiag(0.0); adj = adj.tocsr(); adj.eliminate_zeros()
+    adj_0 = _row_normalise(adj, gcn_norm=undirected)
+    support = [_operator_from_scipy(adj_0)]
+    if k > 1:
+        sq = _operator_from_scipy(adj_0 @ adj_0)
+        support += [sq for _ in range(k - 1)]
+    if bidirectional:
+        support += sgp_spatial_support(adj, k=k)
+    if global_attr:
+        support.append(torch.full((n, n), 1.0 / n))
+    return support
 
 
 def reservoir_preprocessing_(data, hidden_size: int,

@@ -389,3 +389,17 @@ def test_streamed_encoding_equals_single_pass():
     enc.max_device_bytes = 7 * n * (3 + enc.output_size) * 4       # forces 7-step chunks
     chunked = enc(x, ei, ew)
     assert not chunked.is_cuda and torch.equal(chunked, full)
+
+
+def test_spatial_supports_propagate_on_gpu():
+    """sgp_spatial_support's operators applied with ``@`` (the on-the-fly path of
+    lib/dataloader/sgp_dataloader.py:39-71) == the reference's dense supports times x."""
+    z = load("g6_support_bidir_global_k3.npz")
+    n = int(z["n"])
+    sup = sgp_amd.sgp_spatial_support(torch.from_numpy(z["edge_index"]),
+                                      torch.from_numpy(z["edge_weight"]), num_nodes=n, k=3,
+                                      bidirectional=True, global_attr=True)
+    x = torch.randn(4, n, 64)
+    for s, r in zip(sup, torch.from_numpy(z["supports"])):
+        got = (s @ x.cuda()).cpu() if not torch.is_tensor(s) else s @ x
+        close(got, torch.einsum("ij,tjf->tif", r, x))

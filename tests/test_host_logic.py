@@ -261,6 +261,22 @@ def test_encode_dataset_harness_logic(name, tmp_path):
     assert torch.equal(torch.load(path), ds._t["encoded_x"])
 
 
-def test_spatial_support_is_declared_out_of_scope():
-    with pytest.raises(NotImplementedError):
-        sgp_amd.sgp_spatial_support(torch.zeros(2, 0, dtype=torch.long))
+@pytest.mark.parametrize("name", golden_files("g6_"))
+def test_spatial_support_matches_reference(name):
+    """sgp_spatial_support (host-side supports, lib/sgp_preprocessing.py:108-160) against the
+    reference's output, quirks included; oracle restatement checked on the same vectors."""
+    z = load(name)
+    n = int(z["n"])
+    ei = torch.from_numpy(z["edge_index"])
+    ew = torch.from_numpy(z["edge_weight"]) if bool(z["has_weight"]) else None
+    kw = {k: (int(z[k]) if k == "k" else bool(z[k])) for k in
+          ("k", "undirected", "add_self_loops", "remove_self_loops", "bidirectional", "global_attr")
+          if k in z.files}
+    ref = torch.from_numpy(z["supports"])
+    got = sgp_amd.sgp_spatial_support(ei, ew, num_nodes=n, **kw)
+    ora = O.spatial_support_dense(ei, ew, n, **kw)
+    assert len(got) == len(ora) == ref.shape[0]
+    for g, o, r in zip(got, ora, ref):
+        gd = g if torch.is_tensor(g) else g.to_dense()
+        assert torch.allclose(gd, r, rtol=1e-5, atol=1e-6)
+        assert torch.allclose(o.float(), r, rtol=1e-5, atol=1e-6)

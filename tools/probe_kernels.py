@@ -1,5 +1,6 @@
 """Scratch GPU probe (first contact): timings of the kernels on the headline shapes."""
-import sys, time, json
+import os, sys, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sgp_amd
 from sgp_amd import graph, hip, synthetic

@@ -106,14 +106,15 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
  * super-steps ("quad") at a time, gptr[k * 16 + g] .. gptr[k * 16 + g + 1] = quad range:
  *   gw  [quad][q][row i][4]   float   weight of row i for class q's column in super-steps 0..3
  *                                     of the quad (0 = row lacks the column / padding)
- *   gidx[quad][q][4]          uint16  index of that column in the tile's ucol list (0 = padding)
+ *   gidx[quad][q][4]          int32   256 * index of that column in the tile's ucol list, i.e. the
+ *                                     byte offset of its staged row in LDS (0 = padding)
  *   rowmap[64 * k + 4 g + i]  int32   output row of slot i of group g of tile k, -1 = empty
  *                                     (the host may permute rows inside a tile so that the 4
  *                                     rows of a group share most of their columns)
  * Limits: sgp_spmm_mfma_max_union() staged rows per tile, sgp_spmm_mfma_max_quads() quads per
  * tile (weights and indices are LDS-resident). */
 int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
-                      const int32_t* gptr, const uint16_t* gidx, const float* gw,
+                      const int32_t* gptr, const int32_t* gidx, const float* gw,
                       const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,

@@ -314,11 +314,11 @@ int chunk_cap();
 // Weights and row indices are an LDS-resident copy of the group's stream, read 4 super-steps at
 // a time (one ds_read_b128 + one ds_read_b64 per 16 MFMAs); the VALU only forms addresses.
 //   gw   [quad][q][i][4]  float   weight of row i for class q's column in super-steps 4*quad + 0..3
-//   gidx [quad][q][4]     uint16  index of that column in the tile's staged list
+//   gidx [quad][q][4]     int32   LDS byte offset (index in the tile's staged list * 256) of that column
 // (0 / weight 0 padding), gptr[16 * tile + g] .. = quad range of group g.
 struct MfmaArgs {
     const int* trow; const int* uptr; const int* ucol;
-    const int* gptr; const unsigned short* gidx; const float* gw; const int* rowmap;
+    const int* gptr; const int* gidx; const float* gw; const int* rowmap;
     int n_tiles;
     Src src;
     float* Y; long long yrs, ybs;
@@ -328,7 +328,7 @@ struct MfmaArgs {
 
 constexpr int kMfmaPasses = 7;                       // 448 staged rows
 constexpr int kMfmaStageBytes = kMfmaPasses * 64 * 256;
-constexpr int kMfmaQuadBytes = 256 + 32;             // weights + indices of 4 super-steps
+constexpr int kMfmaQuadBytes = 256 + 64;             // weights + row offsets of 4 super-steps
 constexpr int kMfmaMaxQuads = (160 * 1024 - kMfmaStageBytes) / kMfmaQuadBytes;
 
 template <bool HALO, int ABL = 0>
@@ -380,9 +380,9 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
         f32x4* dst = reinterpret_cast<f32x4*>(wlds);
         for (int i = tid; i < tile_quads * 16; i += 1024) dst[i] = src[i];
-        const f32x4* isrc = reinterpret_cast<const f32x4*>(a.gidx) + (long long)tile_q0 * 2;
+        const f32x4* isrc = reinterpret_cast<const f32x4*>(a.gidx) + (long long)tile_q0 * 4;
         f32x4* idst = reinterpret_cast<f32x4*>(ilds);
-        for (int i = tid; i < tile_quads * 2; i += 1024) idst[i] = isrc[i];
+        for (int i = tid; i < tile_quads * 4; i += 1024) idst[i] = isrc[i];
     }
 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // scalar: branches stay uniform
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
     const int n_quads = __builtin_amdgcn_readfirstlane(a.gptr[grp + 1]) - (q_begin + tile_q0);
     const int my_row = a.rowmap[tile * 64 + wave * 4 + q];   // output row of class q (-1: none)
     const char* wmine = wlds + q_begin * 256 + (q * 4 + (lane & 3)) * 16;
-    const char* imine = ilds + q_begin * 32 + q * 8;
+    const char* imine = ilds + q_begin * 64 + q * 16;
     const char* xmine = lds + li * 16;
 
     f32x4 stage[PASSES];
@@ -423,16 +423,16 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
 
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
         f32x4 wn = f32x4{0.f, 0.f, 0.f, 0.f};
-        uint2 in = uint2{0u, 0u};
+        int4 in = int4{0, 0, 0, 0};
         if (n_quads > 0) {
             wn = *reinterpret_cast<const f32x4*>(wmine);
-            in = *reinterpret_cast<const uint2*>(imine);
+            in = *reinterpret_cast<const int4*>(imine);
         }
 #define SGP_SUPER(W, IDX)                                                                       \
         {                                                                                       \
             f32x4 xv;                                                                           \
             if constexpr (ABL == 6) { const float f = __int_as_float((int)(IDX)); xv = f32x4{f, f, f, f}; } \
-            else xv = *reinterpret_cast<const f32x4*>(xmine + ((IDX) << 8));                    \
+            else xv = *reinterpret_cast<const f32x4*>(xmine + (IDX));                           \
             if constexpr (ABL == 5) {                                                           \
                 asm volatile("" :: "v"(xv.x), "v"(xv.y), "v"(xv.z), "v"(xv.w), "v"(W));        \
             } else {                                                                            \
@@ -445,16 +445,16 @@ __global__ __launch_bounds__(1024) void spmm_mfma(MfmaArgs a) {
 #define SGP_QUAD(C)                                                                             \
         {                                                                                       \
             const f32x4 wv = wn;                       /* the next quad's stream is fetched */  \
-            const uint2 ix = in;                       /* under this quad's MFMAs */            \
+            const int4 ix = in;                        /* under this quad's MFMAs */            \
             if ((C) + 1 < n_quads) {                                                            \
                 wn = *reinterpret_cast<const f32x4*>(wmine + ((C) + 1) * 256);                  \
-                in = *reinterpret_cast<const uint2*>(imine + ((C) + 1) * 32);                   \
+                in = *reinterpret_cast<const int4*>(imine + ((C) + 1) * 64);                    \
             }                                                                                   \
             /* padded super-steps carry zero weights: no branch, the MFMA adds 0 */             \
-            SGP_SUPER(wv.x, ix.x & 0xffffu)                                                     \
-            SGP_SUPER(wv.y, ix.x >> 16)                                                         \
-            SGP_SUPER(wv.z, ix.y & 0xffffu)                                                     \
-            SGP_SUPER(wv.w, ix.y >> 16)                                                         \
+            SGP_SUPER(wv.x, ix.x)                                                               \
+            SGP_SUPER(wv.y, ix.y)                                                               \
+            SGP_SUPER(wv.z, ix.z)                                                               \
+            SGP_SUPER(wv.w, ix.w)                                                               \
         }
         // first PASSES quads carry one prefetch load each; the rest run in a plain loop
         if constexpr (ABL != 8 && ABL != 9) {
@@ -671,7 +671,7 @@ int32_t sgp_spmm_mfma_max_union(void) { return kMfmaPasses * 64; }
 int32_t sgp_spmm_mfma_max_quads(void) { return kMfmaMaxQuads; }
 
 int sgp_spmm_mfma_f32(const int32_t* trow, const int32_t* uptr, const int32_t* ucol,
-                      const int32_t* gptr, const uint16_t* gidx, const float* gw,
+                      const int32_t* gptr, const int32_t* gidx, const float* gw,
                       const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t xrs, int64_t xbs,

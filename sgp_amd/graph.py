@@ -224,7 +224,7 @@ class TilePlan:
     max_row_edges: int
     gptr: Optional[torch.Tensor] = None     # int32 [16 * n_tiles + 1], quad ranges of the 4-row groups
     group_fill: float = 0.0                 # useful / issued FMAs of the row-group stream
-    gidx: Optional[torch.Tensor] = None     # uint16 (int16 storage) [n_quads, 4 classes, 4]
+    gidx: Optional[torch.Tensor] = None     # int32 [n_quads, 4 classes, 4] LDS byte offsets
     gw: Optional[torch.Tensor] = None       # float32 [n_quads, 4 classes, 4 rows, 4]
     max_tile_quads: int = 0
     rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
@@ -329,12 +329,39 @@ def cluster_rows_in_tiles(trow, uptr, lcol, row_of_edge):
     return slot_of_row
 
 
+def balance_groups_over_simds(trow, lcol, row_of_edge, slot_of_row):
+    """Permute the 16 row groups of every tile over the wave slots so that the four slot
+    classes s % 4 (the waves that share a SIMD, if the hardware deals a workgroup's waves
+    cyclically -- a speed assumption only) carry about the same number of columns: longest
+    group first, each into the least loaded class that still has room."""
+    n_tiles = len(trow) - 1
+    n_rows = int(trow[-1])
+    tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
+    grp_of_row = tile_of_row * GROUPS_PER_TILE + slot_of_row // GROUP_ROWS
+    key = grp_of_row[row_of_edge] * 65536 + lcol
+    uniq = np.unique(key)
+    counts = np.bincount(uniq >> 16, minlength=n_tiles * GROUPS_PER_TILE).reshape(n_tiles, GROUPS_PER_TILE)
+    order = np.argsort(-counts, axis=1, kind="stable")               # longest first
+    new_slot_of_group = np.empty_like(order)
+    per_class = GROUPS_PER_TILE // 4
+    for k in range(n_tiles):
+        load = np.zeros(4, dtype=np.int64)
+        used = np.zeros(4, dtype=np.int64)
+        for g in order[k]:
+            c = int(np.argmin(np.where(used < per_class, load, np.iinfo(np.int64).max)))
+            new_slot_of_group[k, g] = c + 4 * used[c]
+            load[c] += counts[k, g]
+            used[c] += 1
+    old_group = slot_of_row // GROUP_ROWS
+    return new_slot_of_group[tile_of_row, old_group] * GROUP_ROWS + slot_of_row % GROUP_ROWS
+
+
 def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
     """Row-group stream of ``sgp_spmm_mfma_f32`` (include/sgp_amd.h).  Slot s of a tile belongs
     to group s // 4; for every group: the sorted union of its rows' local column indices,
     dealt round-robin to 4 classes (position p -> super-step p // 4, class p % 4), stored 4
-    super-steps per "quad" as weights ``gw[quad][class][row][4]`` and indices
-    ``gidx[quad][class][4]``."""
+    super-steps per "quad" as weights ``gw[quad][class][row][4]`` and LDS byte offsets of the
+    staged rows ``gidx[quad][class][4]``."""
     n_tiles = len(trow) - 1
     n_rows = int(trow[-1])
     tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
@@ -358,8 +385,8 @@ def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
     quad = gptr[g_s] + p // 16
     sup, cls = (p // 4) % 4, p % 4
     n_quads = int(gptr[-1])
-    gidx = np.zeros((n_quads, 4, 4), dtype=np.uint16)
-    gidx[quad, cls, sup] = (uniq & 0xffff).astype(np.uint16)
+    gidx = np.zeros((n_quads, 4, 4), dtype=np.int32)           # byte offset of the staged row
+    gidx[quad, cls, sup] = ((uniq & 0xffff) * 256).astype(np.int32)
     gw = np.zeros((n_quads, 4, GROUP_ROWS, 4), dtype=np.float32)
     gw[quad[inv], cls[inv], slot_in_group[row_of_edge], sup[inv]] = val
     fill = float(lcol.size) / max(1, n_quads * 16 * GROUP_ROWS)
@@ -409,10 +436,12 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                         int(np.diff(trow).max()), n_tiles, int(n_rows), mu, mre)
         if plan.tile_rows <= GROUP_ROWS * GROUPS_PER_TILE:
             slots = cluster_rows_in_tiles(trow, uptr, lcol, row_of_edge) if cluster else None
+            if slots is not None:
+                slots = balance_groups_over_simds(trow, lcol, row_of_edge, slots)
             gptr, fill, gidx, gw, rowmap = build_group_stream(
                 trow, lcol, row_of_edge, np.asarray(val), slots)
             plan.gptr, plan.group_fill = torch.from_numpy(gptr), fill
-            plan.gidx, plan.gw = torch.from_numpy(gidx.view(np.int16)), torch.from_numpy(gw)
+            plan.gidx, plan.gw = torch.from_numpy(gidx), torch.from_numpy(gw)
             plan.rowmap = torch.from_numpy(rowmap)
             plan.max_tile_quads = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
         return plan

@@ -116,7 +116,7 @@ class HipOps:
 class HaloExchange:
     """Per-hop exchange of the rows peers reference.  Buffers are ``[rows, T, D]`` so that
     ``all_to_all_single`` splits them along dim 0; the SpMM reads the receive buffer in place
-    through its (row, batch) strides."""
+    through its (row, batch) strides.  One instance per (operator, time chunk)."""
 
     def __init__(self, block: LocalBlock, group=None, ops=HipOps):
         self.block, self.group, self.ops = block, group, ops
@@ -152,29 +152,84 @@ class HaloExchange:
 
 class PartitionedSpatial:
     """K-hop propagation + global mean of ``SGPSpatialEncoder.encode_into`` for the local
-    node block: fills ``out[T, n_own, P * feat]`` in place (block 0 already written)."""
+    node block: fills ``out[T, n_own, P * feat]`` in place (block 0 already written).
+
+    On GPUs the time axis is cut into ``n_chunks`` pieces and the hop loop is software-pipelined
+    over (hop, chunk): the row packing + all_to_all of a chunk run on a communication stream
+    while the SpMM of the previous chunk runs on the compute stream, and hop h+1 of a chunk
+    starts as soon as hop h of THAT chunk is done (time steps are independent in the
+    propagation).  xGMI is point-to-point, so the exchange costs about as much as a hop's
+    compute at 8 GPUs; hidden behind it, scaling stays close to the compute curve."""
 
     def __init__(self, blocks: List[LocalBlock], receptive_field, global_attr, n_total,
-                 group=None, ops=HipOps):
+                 group=None, ops=HipOps, n_chunks=4):
         self.blocks = blocks                       # forward (+ backward) local blocks
         self.k, self.global_attr, self.n_total = receptive_field, global_attr, n_total
         self.group, self.ops = group, ops
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.exchanges = [HaloExchange(b, group, ops) for b in blocks]
+        self.n_chunks = max(1, int(n_chunks))
+        self._xchg = {}
+        self._comm_stream = None
 
     def num_blocks(self):
         return 1 + len(self.blocks) * self.k + (1 if self.global_attr else 0)
 
-    def encode_into(self, out, feat):
-        for d, (blk, xchg) in enumerate(zip(self.blocks, self.exchanges)):
+    def _exchange(self, d, j):
+        key = (d, j)
+        if key not in self._xchg:
+            self._xchg[key] = HaloExchange(self.blocks[d], self.group, self.ops)
+        return self._xchg[key]
+
+    def _hops_serial(self, out, feat):
+        for d, blk in enumerate(self.blocks):
             src = out[:, :, 0:feat]
             for h in range(self.k):
                 s = 1 + d * self.k + h
                 dst = out[:, :, s * feat:(s + 1) * feat]
                 # every rank enters the collective, even one whose block has no halo
-                halo = xchg(src) if self.world_size > 1 else None
+                halo = self._exchange(d, 0)(src) if self.world_size > 1 else None
                 self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
                 src = dst
+
+    def _hops_pipelined(self, out, feat):
+        T = out.shape[0]
+        nc = min(self.n_chunks, T)
+        cuts = [(T * j) // nc for j in range(nc + 1)]
+        main = torch.cuda.current_stream(out.device)
+        if self._comm_stream is None:
+            self._comm_stream = torch.cuda.Stream(device=out.device)
+        comm = self._comm_stream
+        start = torch.cuda.Event()
+        start.record(main)                          # block 0 (reservoir states) is complete
+        for d, blk in enumerate(self.blocks):
+            ready = [start] * nc                    # source slot of chunk j is written
+            for h in range(self.k):
+                s_src = 0 if h == 0 else 1 + d * self.k + h - 1
+                s_dst = 1 + d * self.k + h
+                done = []
+                for j in range(nc):
+                    t0, t1 = cuts[j], cuts[j + 1]
+                    src = out[t0:t1, :, s_src * feat:(s_src + 1) * feat]
+                    dst = out[t0:t1, :, s_dst * feat:(s_dst + 1) * feat]
+                    with torch.cuda.stream(comm):
+                        comm.wait_event(ready[j])
+                        halo = self._exchange(d, j)(src)
+                        got = torch.cuda.Event()
+                        got.record(comm)
+                    main.wait_event(got)
+                    self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    done.append(ev)
+                ready = done
+        # the communication stream's buffers are reused by the next call: let it catch up
+        comm.wait_stream(main)
+
+    def encode_into(self, out, feat):
+        if self.world_size > 1 and out.is_cuda and self.n_chunks > 1 and out.shape[0] >= 8:
+            self._hops_pipelined(out, feat)
+        else:
+            self._hops_serial(out, feat)
         if self.global_attr:
             p = self.num_blocks() - 1
             sums = self.ops.node_sums(out[:, :, :feat])
@@ -191,7 +246,7 @@ class PartitionedSpatial:
 
 def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
                              rank=None, world_size=None, group=None, ops=HipOps,
-                             balance="rows"):
+                             balance="rows", n_chunks=4):
     """Split the forward (and backward) global operators for this rank."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
@@ -199,4 +254,5 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
     bounds = partition_bounds(n, world_size,
                               ops_global[0].rowptr.numpy() if balance == "nnz" else None)
     blocks = [split_operator(op, bounds, rank) for op in ops_global]
-    return PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops), bounds
+    return PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
+                              n_chunks=n_chunks), bounds

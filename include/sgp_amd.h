@@ -156,6 +156,45 @@ int sgp_reservoir_f32(const float* x, int64_t x_row_stride, int64_t x_step_strid
                       int32_t T, int32_t N, int32_t F, int32_t R,
                       sgp_stream_t stream);
 
+/* --------------------------------------------------------------- DynGESN ---
+ * The graph echo-state baseline (lib/nn/reservoir/graph_reservoir.py:85-93, stepped by
+ * tsl/nn/blocks/encoders/gcrnn.py:67-93):
+ *     h' = (1 - alpha) h + alpha * act( x W_ih^T + b + A_hat (h W_hh^T) )
+ * sgp_gesn_f32 runs a whole sequence through all L layers (the _GraphRNN loop of gcrnn.py:67-93
+ * with _cat_states_layers): two launches per (time step, layer), issued from C:
+ *   x:   [T, N, F] strides (x_step_stride, x_row_stride, 1)
+ *   out: [T, N, L*R] strides (out_step_stride, out_row_stride, 1); layer i fills columns
+ *        i*R .. (i+1)*R-1 of every step
+ *   w_ih / w_hh / b / alpha: HOST arrays of length L; w_ih[i] ([R, F] for i = 0, else [R, R]),
+ *        w_hh[i] ([R, R]) and b[i] ([R]) are DEVICE pointers to the reference's parameters
+ *        (graph_reservoir.py:44-52), alpha[i] the layer's leaking rate
+ *   h_state: [L, N, R] contiguous, initial states in, final states out (zeros = cold start)
+ *   workspace: sgp_gesn_workspace_bytes(N, R, L) bytes of device scratch, 16-byte aligned
+ *   rowptr / col / val: the normalised operator in CSR, rows = targets (N rows)
+ * Building blocks, also exported (one cell step = graph_reservoir.py:85-93):
+ *   sgp_gemm_nt_f32      C[m, n] = sum_k A[m, k] W[n, k] (+ bias[n])   (F.linear; fp32 MFMA)
+ *   sgp_gesn_update_f32  h_out[i, :] = (1 - alpha) h_in[i, :]
+ *                                     + alpha * act(p[i, :] + sum_e val[e] z[col[e], :])
+ *                        (torch_sparse matmul of :91 fused with activation and leak; also
+ *                        writes the row into out_row[i * out_stride + 0:R], the step's slot of
+ *                        the [T, N, L*R] embedding).  z, p, h_in, h_out: contiguous [N, R].
+ */
+int64_t sgp_gesn_workspace_bytes(int32_t N, int32_t R, int32_t L);
+int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                 const float* x, int64_t x_row_stride, int64_t x_step_stride,
+                 const float* const* w_ih, const float* const* w_hh, const float* const* b,
+                 const double* alpha, int32_t act,
+                 float* out, int64_t out_row_stride, int64_t out_step_stride,
+                 float* h_state, void* workspace,
+                 int32_t T, int32_t N, int32_t F, int32_t R, int32_t L, sgp_stream_t stream);
+int sgp_gemm_nt_f32(const float* A, int64_t lda, const float* W, int64_t ldw, const float* bias,
+                    float* C, int64_t ldc, int32_t M, int32_t N, int32_t K, sgp_stream_t stream);
+int sgp_gesn_update_f32(const int32_t* rowptr, const int32_t* col, const float* val,
+                        const float* z, const float* p, const float* h_in,
+                        double alpha, int32_t act,
+                        float* h_out, float* out_row, int64_t out_stride,
+                        int32_t n_nodes, int32_t R, sgp_stream_t stream);
+
 /* ------------------------------------------------------------ Node mean ----
  * Y[b, i, 0:feat] = (1 / n_rows) * sum_j X[b, j, 0:feat]   for every i.
  * With partial != NULL the kernel instead writes the un-normalised column sums

@@ -256,6 +256,36 @@ def main():
              n_calls=np.int64(len(out.calls)),
              get_tensors_keys=np.array(out.calls[0][1]))
 
+    # ---- G3b: more DynGESN cases (own generator: appended after the others) ----
+    g3 = torch.Generator().manual_seed(4321)
+    gesn_cases = {
+        "relu_r40": dict(reservoir_size=40, reservoir_layers=2, leaking_rate=.8,
+                         spectral_radius=.9, density=.7, input_scaling=1.5,
+                         alpha_decay=False, reservoir_activation="relu"),
+        "selfnorm_r24": dict(reservoir_size=24, reservoir_layers=2, leaking_rate=.9,
+                             spectral_radius=.8, density=.9, input_scaling=1.,
+                             alpha_decay=True, reservoir_activation="self_norm"),
+        "shipped_r80": dict(reservoir_size=80, reservoir_layers=3, leaking_rate=.9,
+                            spectral_radius=.9, density=.7, input_scaling=1.,
+                            alpha_decay=False, reservoir_activation="tanh"),
+    }
+    for idx, (name, kw) in enumerate(gesn_cases.items()):
+        n3, t3, f3 = (21, 12, 2) if idx else (16, 20, 3)
+        ei3, ew3 = graph(n3, 5 * n3, seed=30 + idx, isolated=(idx != 2))
+        torch.manual_seed(310 + idx)
+        enc = ref.GESNEncoder(input_size=f3, **kw)
+        x3 = torch.randn(t3, n3, f3, generator=g3)
+        w3 = ew3                      # edge_weight=None is a TypeError in the reference (:39)
+        y3 = enc(x3, ei3, w3)
+        save(f"g3_gesn_{name}", x=x3.numpy(), edge_index=ei3.numpy(),
+             edge_weight=(ew3.numpy() if w3 is not None else np.zeros(0, np.float32)),
+             has_weight=np.bool_(w3 is not None), y=y3.numpy(),
+             activation=np.array(kw["reservoir_activation"]), seed=np.int64(310 + idx),
+             cfg=np.array([f3, kw["reservoir_size"], kw["reservoir_layers"], kw["leaking_rate"],
+                           kw["spectral_radius"], kw["density"], kw["input_scaling"],
+                           float(kw["alpha_decay"])]),
+             **layer_dump(enc.reservoir))
+
 
 if __name__ == "__main__":
     main()

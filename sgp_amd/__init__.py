@@ -4,8 +4,8 @@ Python surface.  Compute lives in ``csrc/libsgp_amd.so`` (hand-written HIP for g
 is no CPU fallback."""
 from . import hip
 from .graph import ShiftOperator
-from .nn.encoders import SGPEncoder, SGPSpatialEncoder, SGPTemporalEncoder
-from .nn.reservoir import Reservoir, ReservoirLayer
+from .nn.encoders import GESNEncoder, SGPEncoder, SGPSpatialEncoder, SGPTemporalEncoder
+from .nn.reservoir import GESNLayer, GraphESN, Reservoir, ReservoirLayer
 from .sgp_preprocessing import (preprocess_adj, preprocess_dataset, reservoir_preprocessing_,
                                 sgp_spatial_embedding, sgp_spatial_support)
 from .utils import encode_dataset, self_normalizing_activation

@@ -52,6 +52,14 @@ SIGNATURES = {
                                          c_p, c_i64, c_i64,
                                          c_p, c_p,
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_gesn_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgp_gesn_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
+                                    c_p, c_i64, c_i64, c_p, c_p,
+                                    c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_gemm_nt_f32": (ctypes.c_int, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_i64,
+                                       c_i32, c_i32, c_i32, c_p]),
+    "sgp_gesn_update_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_f64, c_i32,
+                                           c_p, c_p, c_i64, c_i32, c_i32, c_p]),
     "sgp_node_mean_bcast_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
                                                c_p, c_i64, c_i64, c_p,
                                                c_i32, c_i32, c_i32, c_p]),
@@ -234,6 +242,58 @@ def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
         h_state.data_ptr() if h_state is not None else None, ws.data_ptr(),
         T, N, F, R, _stream(x)), "sgp_reservoir_f32")
     return out
+
+
+# ---------------------------------------------------------------- DynGESN
+def gesn_sequence(rowptr, col, val, x, weights, alphas, activation, out, h_state):
+    """Whole DynGESN sequence: x[T, N, F] -> out[T, N, L*R]; ``weights`` is a list of
+    (w_ih, w_hh, b) device tensors per layer, ``h_state`` [L, N, R] is updated in place."""
+    lib = require_gpu()
+    T, n, f = x.shape
+    L = len(weights)
+    r = weights[0][1].shape[0]
+    assert x.stride(2) == 1 and out.stride(2) == 1 and out.shape == (T, n, L * r)
+    assert h_state.is_contiguous() and tuple(h_state.shape) == (L, n, r)
+    for i, (w_ih, w_hh, b) in enumerate(weights):
+        assert w_ih.is_contiguous() and w_hh.is_contiguous() and b.is_contiguous()
+        assert tuple(w_ih.shape) == (r, f if i == 0 else r) and tuple(w_hh.shape) == (r, r)
+    ptrs = lambda k: (ctypes.c_void_p * L)(*[w[k].data_ptr() for w in weights])
+    al = (ctypes.c_double * L)(*[float(a) for a in alphas])
+    ws = torch.empty(max(16, lib.sgp_gesn_workspace_bytes(n, r, L)) // 4, dtype=torch.float32,
+                     device=x.device)
+    _check(lib.sgp_gesn_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(),
+                            x.data_ptr(), x.stride(1), x.stride(0), ptrs(0), ptrs(1), ptrs(2), al,
+                            ACT_CODES[activation], out.data_ptr(), out.stride(1), out.stride(0),
+                            h_state.data_ptr(), ws.data_ptr(), T, n, f, r, L, _stream(x)),
+           "sgp_gesn_f32")
+    return out
+
+
+def gemm_nt(a, w, bias, out):
+    """out[m, n] = sum_k a[m, k] w[n, k] (+ bias[n]); 2-D float32 CUDA, unit inner strides."""
+    lib = require_gpu()
+    assert a.dim() == 2 and w.dim() == 2 and out.dim() == 2 and a.shape[1] == w.shape[1]
+    assert a.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    _check(lib.sgp_gemm_nt_f32(a.data_ptr(), a.stride(0), w.data_ptr(), w.stride(0),
+                               bias.data_ptr() if bias is not None else None,
+                               out.data_ptr(), out.stride(0), a.shape[0], w.shape[0], a.shape[1],
+                               _stream(a)), "sgp_gemm_nt_f32")
+    return out
+
+
+def gesn_update(rowptr, col, val, z, p, h_in, alpha, activation, h_out, out_rows):
+    """DynGESN state update for one (step, layer); ``out_rows`` is the [N, R] slot (row stride
+    arbitrary) of the embedding that receives the new state."""
+    lib = require_gpu()
+    n, r = h_in.shape
+    for t in (z, p, h_in, h_out):
+        assert t.is_contiguous() and tuple(t.shape) == (n, r)
+    assert out_rows.shape == (n, r) and out_rows.stride(1) == 1
+    _check(lib.sgp_gesn_update_f32(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(),
+                                   z.data_ptr(), p.data_ptr(), h_in.data_ptr(), float(alpha),
+                                   ACT_CODES[activation], h_out.data_ptr(), out_rows.data_ptr(),
+                                   out_rows.stride(0), n, r, _stream(z)), "sgp_gesn_update_f32")
+    return h_out
 
 
 # ---------------------------------------------------------------- helpers

@@ -1,1 +1,2 @@
 from .reservoir import Reservoir, ReservoirLayer
+from .graph_reservoir import GraphESN, GESNLayer

@@ -238,6 +238,107 @@ def test_full_encoder_golden(name):
     close(y, z["y"])
 
 
+# ------------------------------------------------------------------ DynGESN baseline
+def set_gesn_weights(res, layers):
+    for l, g in zip(res.rnn_cells, layers):
+        l.w_ih.data.copy_(g["w_ih"]); l.w_hh.data.copy_(g["w_hh"]); l.b_ih.data.copy_(g["b_ih"])
+        assert float(l.alpha) == g["alpha"]
+
+
+@pytest.mark.parametrize("name", golden_files("g3_gesn"))
+def test_gesn_encoder_golden(name):
+    z = load(name)
+    layers = O.layers_from_npz(z)
+    if "cfg" in z:
+        f, r, L, a, rho, dens, scale, dec = z["cfg"]
+        act = str(z["activation"])
+    else:
+        f, r, L, a, rho, dens, scale, dec, act = 3, 32, 3, .9, .9, 1., 1., True, "tanh"
+    enc = sgp_amd.GESNEncoder(int(f), int(r), int(L), a, rho, dens, scale, bool(dec),
+                              reservoir_activation=act)
+    set_gesn_weights(enc.reservoir, layers)
+    y = enc(torch.from_numpy(z["x"]), torch.from_numpy(z["edge_index"]),
+            torch.from_numpy(z["edge_weight"]))
+    assert not y.is_cuda
+    close(y, z["y"])
+    if "seed" in z:                         # same seed -> the reference's weights
+        torch.manual_seed(int(z["seed"]))
+        enc2 = sgp_amd.GESNEncoder(int(f), int(r), int(L), a, rho, dens, scale, bool(dec),
+                                   reservoir_activation=act)
+        close(enc2(torch.from_numpy(z["x"]).cuda(), torch.from_numpy(z["edge_index"]),
+                   torch.from_numpy(z["edge_weight"])), z["y"])
+
+
+@pytest.mark.parametrize("n,f,r,L,act", [(207, 2, 320, 3, "tanh"), (50, 1, 100, 2, "relu"),
+                                          (33, 4, 512, 1, "self_norm"), (1, 3, 16, 2, "tanh")])
+def test_gesn_against_oracle(n, f, r, L, act):
+    """Shipped METR-LA shape (config/traffic/gesn.yaml: 320 units x 3 layers) and edge sizes."""
+    torch.manual_seed(n)
+    ei, ew = synthetic.sparse_traffic_graph(n, max(1, 7 * n), seed=n) if n > 1 else \
+        (torch.zeros(2, 1, dtype=torch.long), torch.ones(1))
+    enc = sgp_amd.GESNEncoder(f, r, L, .9, .9, .7, 1., True, reservoir_activation=act)
+    x = torch.randn(24, n, f)
+    y = enc(x, ei, ew)
+    layers = [dict(w_ih=l.w_ih.data, w_hh=l.w_hh.data, b_ih=l.b_ih.data, alpha=float(l.alpha))
+              for l in enc.reservoir.rnn_cells]
+    ref = O.gesn_forward(x, ei, ew, layers, activation=act)
+    # deep layers sum R O(1) terms per pre-activation (w_ih of layer > 0 is U(-1, 1) over R
+    # inputs), so fp32 evaluations differ by ~R * 2^-24 before the activation: the bar is the
+    # fp32 oracle's own distance to the fp64 evaluation, and 1e-5 where that distance allows
+    ref64 = O.gesn_forward(x, ei, ew, layers, activation=act, dtype=torch.float64)
+    e_gpu = float((y.double() - ref64).abs().max())
+    e_cpu = float((ref.double() - ref64).abs().max())
+    assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
+    tol = max(1e-5, 4 * e_cpu)
+    close(y, ref, rtol=tol, atol=tol, fro=1e-5)
+
+
+def test_graph_esn_module_and_layer_step():
+    torch.manual_seed(9)
+    n, f, r = 40, 3, 48
+    ei, ew = synthetic.sparse_traffic_graph(n, 200, seed=1)
+    from sgp_amd.nn.encoders.dyn_gesn_encoder import gesn_operator
+    op = gesn_operator(ei, ew, n)
+    res = sgp_amd.GraphESN(f, r, num_layers=2, alpha_decay=True)
+    x = torch.randn(2, 10, n, f)
+    out, h = res(x, op)
+    assert out.shape == (2, 10, n, 2 * r) and h.shape == (2, 2, n, r)
+    layers = [dict(w_ih=l.w_ih.data, w_hh=l.w_hh.data, b_ih=l.b_ih.data, alpha=float(l.alpha))
+              for l in res.rnn_cells]
+    a = op.to_dense()
+    for b in range(2):
+        hs = [torch.zeros(n, r) for _ in layers]
+        for t in range(10):
+            u = x[b, t]
+            for i, l in enumerate(layers):
+                pre = torch.nn.functional.linear(u, l["w_ih"], l["b_ih"]) + \
+                    a @ torch.nn.functional.linear(hs[i], l["w_hh"])
+                u = (1 - l["alpha"]) * hs[i] + l["alpha"] * torch.tanh(pre)
+                hs[i] = u
+            close(out[b, t], torch.cat(hs, -1), fro=2e-5)
+        close(h[:, b], torch.stack(hs), fro=2e-5)
+    # continuing from the returned state == running the longer sequence
+    out2, _ = res(x[:, 5:], op, h=list(res(x[:, :5], op)[1]))
+    close(out2, out[:, 5:])
+    # a single cell step
+    cell = res.rnn_cells[0]
+    h0 = torch.randn(n, r)
+    pre = torch.nn.functional.linear(x[0, 0], cell.w_ih, cell.b_ih) + \
+        a @ torch.nn.functional.linear(h0, cell.w_hh)
+    close(cell(x[0, 0], h0, op), (1 - cell.alpha) * h0 + cell.alpha * torch.tanh(pre))
+
+
+def test_gemm_nt_edges():
+    torch.manual_seed(2)
+    for m, n, k in [(1, 1, 1), (17, 33, 5), (100, 320, 320), (64, 16, 3), (0, 8, 4),
+                    (37, 50, 64), (16, 16, 16), (5, 7, 336), (9, 20, 0)]:
+        a, w, b = torch.randn(m, k), torch.randn(n, k), torch.randn(n)
+        out = torch.empty(m, n, device="cuda")
+        hip.gemm_nt(a.cuda(), w.cuda(), b.cuda(), out)
+        ref = (a.double() @ w.double().T + b.double()).float()
+        close(out, ref, rtol=1e-5, atol=1e-5 * max(1, k) ** .5)
+
+
 def test_temporal_encoder_ignores_graph():
     torch.manual_seed(4)
     enc = sgp_amd.SGPTemporalEncoder(3, reservoir_size=32, reservoir_layers=2)

@@ -280,3 +280,43 @@ def test_spatial_support_matches_reference(name):
         gd = g if torch.is_tensor(g) else g.to_dense()
         assert torch.allclose(gd, r, rtol=1e-5, atol=1e-6)
         assert torch.allclose(o.float(), r, rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ DynGESN host side
+def test_graph_esn_seed_reproduces_reference_weights():
+    """graph_reservoir.py:140 -- GraphESN draws every layer twice; the seed still matches."""
+    z = load("g4_seed_gesn.npz")
+    torch.manual_seed(int(z["seed"]))
+    res = sgp_amd.GraphESN(input_size=3, hidden_size=16, num_layers=2, density=.8,
+                           alpha_decay=True)
+    after = torch.rand(4)
+    for layer, g in zip(res.rnn_cells, O.layers_from_npz(z)):
+        assert torch.equal(layer.w_ih.data, g["w_ih"])
+        assert torch.equal(layer.w_hh.data, g["w_hh"])
+        assert torch.equal(layer.b_ih.data, g["b_ih"])
+        assert float(layer.alpha) == g["alpha"]
+    assert torch.equal(after, torch.from_numpy(z["rng_after"]))
+
+
+@pytest.mark.parametrize("name", golden_files("g3_gesn"))
+def test_gesn_operator_matches_oracle(name):
+    from sgp_amd.nn.encoders.dyn_gesn_encoder import gesn_operator
+    z = load(name)
+    n = z["x"].shape[1]
+    op = gesn_operator(z["edge_index"], torch.from_numpy(z["edge_weight"]), n)
+    ref = O.gesn_operator_dense(z["edge_index"], torch.from_numpy(z["edge_weight"]), n)
+    assert torch.allclose(op.to_dense().double(), ref, rtol=1e-6, atol=1e-7)
+
+
+def test_gesn_encoder_surface():
+    import argparse
+    from sgp_amd.nn.encoders.dyn_gesn_encoder import gesn_operator
+    p = sgp_amd.GESNEncoder.add_model_specific_args(argparse.ArgumentParser())
+    a = p.parse_args([])
+    assert (a.reservoir_size, a.reservoir_layers, a.density, a.alpha_decay) == (32, 1, .7, False)
+    with pytest.raises(TypeError):           # the reference divides None by the degree (:39)
+        gesn_operator(torch.zeros(2, 3, dtype=torch.long), None, 4)
+    with pytest.raises(NotImplementedError):
+        sgp_amd.GESNLayer(3, 8, aggr="mean")
+    enc = sgp_amd.GESNEncoder(3, 8, 2, .9, .9, .7, 1., True)
+    assert [float(c.alpha) for c in enc.reservoir.rnn_cells] == [.9, .8]

@@ -83,11 +83,13 @@ def test_full_encoder(name):
         close(y, z["y"])
 
 
-def test_gesn():
-    z = load("g3_gesn.npz")
+@pytest.mark.parametrize("name", golden_files("g3_gesn"))
+def test_gesn(name):
+    z = load(name)
     layers = O.layers_from_npz(z)
+    act = str(z["activation"]) if "activation" in z else "tanh"
     y = O.gesn_forward(torch.from_numpy(z["x"]), z["edge_index"],
-                       torch.from_numpy(z["edge_weight"]), layers)
+                       torch.from_numpy(z["edge_weight"]), layers, activation=act)
     close(y, z["y"])
 
 

@@ -1,0 +1,19 @@
+"""Time the DynGESN baseline encoder on the shipped METR-LA shape (config/traffic/gesn.yaml)."""
+import sys, time
+import torch
+import sgp_amd
+from sgp_amd import synthetic
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+n, f, r, L = 207, 2, 320, 3
+ei, ew = synthetic.sparse_traffic_graph(n, 1515, seed=0)
+torch.manual_seed(0)
+enc = sgp_amd.GESNEncoder(f, r, L, .9, .9, .7, 1., True)
+x = torch.randn(T, n, f, device="cuda")
+enc(x[:50], ei, ew)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+y = enc(x, ei, ew)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"gesn T={T} N={n} R={r} L={L}: {dt*1e3:.1f} ms, {dt/T*1e6:.1f} us/step, {T*n/dt:.3e} node-steps/s")

@@ -126,6 +126,27 @@ int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const in
 int32_t sgp_spmm_mfma_max_union(void);
 int32_t sgp_spmm_mfma_max_quads(void);
 
+/* Two-phase pipelined form of the row-group kernel (same tiles, groups, classes and arithmetic).
+ * The tile's distinct-column list is cut at usplit[k] (a multiple of 4) into segment A (list
+ * positions < usplit[k]) and segment B; a group's quads are stored A-part first and never mix
+ * the segments: gptr[2 (16 k + g)] .. gptr[2 (16 k + g) + 1] = quads on segment A,
+ * .. gptr[2 (16 k + g) + 2] = quads on segment B.  Per time step the kernel refills one segment
+ * of the LDS stage by LDS-DMA (global_load_lds_dwordx4) while the matrix cores consume the other.
+ * gidx / gw / rowmap as for sgp_spmm_mfma_f32.  Limits: sgp_spmm_pipe_max_union() staged rows
+ * per tile, sgp_spmm_pipe_max_quads() quads per tile. */
+int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+                      const int32_t* gptr, const int32_t* gidx, const float* gw,
+                      const int32_t* rowmap,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
+                      const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                      const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                      int32_t n_own,
+                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                      sgp_stream_t stream);
+int32_t sgp_spmm_pipe_max_union(void);
+int32_t sgp_spmm_pipe_max_quads(void);
+
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and
  * largest padded per-row edge count. */

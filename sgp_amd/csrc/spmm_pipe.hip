@@ -1,0 +1,411 @@
+// Pipelined matrix-core row-group SpMM (reference call site: lib/sgp_preprocessing.py:202,
+// x = adj @ x).  gfx950 / wave64 only.  Same arithmetic as spmm_mfma (spmm.hip): a wave owns 4
+// output rows, walks the sorted union of their columns 4 column classes at a time and feeds
+// v_mfma_f32_4x4x1_16b_f32 (exact fp32).  What differs is how a time step moves through the CU:
+//
+//   * the tile's staged source rows never pass through registers: every wave issues
+//     global_load_lds_dwordx4 (16 B per lane, 4 staged rows = 1 KiB per wave instruction) and the
+//     data lands in LDS behind the compute of the previous phase;
+//   * the tile's distinct-column list is cut in two SEGMENTS (A = the first uA rows, B = the
+//     rest), every group's stream is stored A-part first; a time step is two phases
+//         barrier, DMA B(t)   -> region B | MFMAs on region A
+//         barrier, DMA A(t+1) -> region A | MFMAs on region B, fold, store
+//     so one half of the stage is being refilled while the other is consumed and the DMA has a
+//     whole phase (~1.5 us) to land: 2 barriers per step, no ds_write pass, no staging VGPRs;
+//   * the operand reads are software-pipelined one quad ahead inside a wave (weights/indices two
+//     quads ahead), so the LDS latency sits under the wave's own MFMAs instead of being exposed
+//     every time the 4 waves of a SIMD fall into step at a barrier.
+#include "common.h"
+#include <stdlib.h>
+
+using sgp::f32x4;
+
+namespace {
+
+struct Src2 {
+    const float* x;  long long xrs, xbs;
+    const float* xh; long long xhrs, xhbs;
+    int n_own;
+};
+
+struct PipeArgs {
+    const int* uptr; const int* ucol; const int* usplit;
+    const int* gptr;                       // [32 * n_tiles + 1]: (A, B) quad ranges per group
+    const int* gidx; const float* gw; const int* rowmap;
+    int n_tiles;
+    Src2 src;
+    float* Y; long long yrs, ybs;
+    int n_rows, batch, feat;
+    int t_chunk, n_tchunks;
+    int map;
+    unsigned* dbg;                         // timeline stamps (ablation builds only)
+};
+
+constexpr int kPasses = 7;                               // 448 staged rows
+constexpr int kStageBytes = kPasses * 64 * 256;
+constexpr int kQuadBytes = 256 + 64;
+// the offset prefetch runs up to 3 quads past a wave's last quad (the offsets sit last in LDS;
+// what is fetched there is never used)
+constexpr int kSlackBytes = 3 * 64;
+constexpr int kMaxQuads = (160 * 1024 - kStageBytes - kSlackBytes) / kQuadBytes;
+
+// LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to 1 KiB of LDS at `lds_off`
+// (wave-uniform byte address, via M0).  Issued from asm so that hipcc's s_waitcnt bookkeeping does
+// not know about it: the compiler would otherwise drain vmcnt(0) in front of every ds_read that
+// follows.  Completion is counted by hand (s_waitcnt vmcnt(0) before the phase barrier).
+__device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+__device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(vaddr), "s"(lds_off) : "memory");
+}
+
+template <bool HALO, int ABL = 0>
+__global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    // XCD-aware decode (workgroup ids are dealt round-robin to the 8 XCDs -- a speed assumption
+    // only).  map 0: XCD x sweeps the tiles of "its" time chunks; map 1: every XCD owns a
+    // contiguous 1/8 of the tiles and all XCDs walk the time chunks together, so that the rows
+    // an XCD re-fetches at the edge of its tile range were recently fetched by its neighbour
+    // (Infinity Cache) instead of coming from HBM again.
+    const int orig = blockIdx.x;
+    const int xcd = orig & 7;
+    int tile, tchunk, wg;
+    if (a.map == 0) {
+        const int nwg = a.n_tiles * a.n_tchunks;
+        const int qq = nwg >> 3, rr = nwg & 7;
+        wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+        tile = wg % a.n_tiles;
+        tchunk = wg / a.n_tiles;
+    } else {
+        const int tq = a.n_tiles >> 3, tr = a.n_tiles & 7;
+        const int t0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+        const int cnt = tq + (xcd < tr ? 1 : 0);
+        const int local = orig >> 3;
+        if (local >= cnt * a.n_tchunks) return;
+        tchunk = local / cnt;
+        tile = t0 + local % cnt;
+        wg = tchunk * a.n_tiles + tile;
+    }
+    const int f_base = blockIdx.y * 64;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = tid & 15;
+    const int eg = tid >> 4;
+    const int q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int u0 = a.uptr[tile];
+    const int nU = a.uptr[tile + 1] - u0;
+    const int uA = a.usplit[tile];                       // rows of segment A (multiple of 4)
+
+    const int t_begin = tchunk * a.t_chunk;
+    const int t_end = min(a.batch, t_begin + a.t_chunk);
+    if (t_begin >= t_end) return;
+
+    // per-lane source of every staged row this lane feeds: byte offset from the step base
+    unsigned voff[kPasses];
+    unsigned halo_mask = 0;
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const int u = p * 64 + eg;
+        const int c = (u < nU) ? a.ucol[u0 + u] : (nU > 0 ? a.ucol[u0] : 0);
+        if (HALO && c >= a.src.n_own) {
+            halo_mask |= 1u << p;
+            voff[p] = (unsigned)((c - a.src.n_own) * (int)a.src.xhrs + f_base + li * 4) * 4u;
+        } else {
+            voff[p] = (unsigned)(c * (int)a.src.xrs + f_base + li * 4) * 4u;
+        }
+    }
+
+    // the tile's stream -> LDS (once per workgroup): weights then indices
+    const int tile_q0 = a.gptr[tile * 32], tile_q1 = a.gptr[tile * 32 + 32];
+    const int tile_quads = tile_q1 - tile_q0;
+    char* wlds = lds + kStageBytes;
+    char* ilds = wlds + tile_quads * 256;
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
+        f32x4* dst = reinterpret_cast<f32x4*>(wlds);
+        for (int i = tid; i < tile_quads * 16; i += 1024) dst[i] = src[i];
+        const f32x4* isrc = reinterpret_cast<const f32x4*>(a.gidx) + (long long)tile_q0 * 4;
+        f32x4* idst = reinterpret_cast<f32x4*>(ilds);
+        for (int i = tid; i < tile_quads * 4; i += 1024) idst[i] = isrc[i];
+    }
+
+    const int grp = (tile * 16 + wave) * 2;
+    const int gA = __builtin_amdgcn_readfirstlane(a.gptr[grp]) - tile_q0;
+    const int gB = __builtin_amdgcn_readfirstlane(a.gptr[grp + 1]) - tile_q0;
+    const int gE = __builtin_amdgcn_readfirstlane(a.gptr[grp + 2]) - tile_q0;
+    const int nA = gB - gA, nB = gE - gB;
+    const int my_row = a.rowmap[tile * 64 + wave * 4 + q];   // output row of class q (-1: none)
+    const char* wA = wlds + gA * 256 + (q * 4 + (lane & 3)) * 16;
+    const char* iA = ilds + gA * 64 + q * 16;
+    const char* wB = wA + nA * 256;
+    const char* iB = iA + nA * 64;
+    const char* xmine = lds + li * 16;
+    // debug timeline (ABL & 32): workgroup `dbg[0]` records s_memtime at 8 points of 4 steps
+    auto stamp = [&](int t, int point) {
+        if constexpr (ABL & 32) {
+            const int ts = t - t_begin - 8;
+            if (wg == 777 && ts >= 0 && ts < 4) {
+                const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+                if (lane == 0) a.dbg[((ts * 16 + wave) * 8 + point)] = now;
+            }
+        }
+    };
+
+    // DMA of one segment of step t: wave w moves staged rows 64 p + 4 w .. + 3 (one 1-KiB piece)
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    auto dma_segment = [&](int t, bool seg_b) {
+        if constexpr (ABL & 1) return;                    // ablation: no staging traffic
+        if constexpr (ABL & 4) t = t_begin;               // ablation: staging hits L2
+        const char* xt = reinterpret_cast<const char*>(a.src.x + (long long)t * a.src.xbs);
+        const char* ht = reinterpret_cast<const char*>(a.src.xh + (long long)t * a.src.xhbs);
+#pragma unroll
+        for (int p = 0; p < kPasses; ++p) {
+            const int r0 = p * 64 + wave * 4;             // scalar
+            const bool mine = seg_b ? (r0 >= uA && r0 < nU) : (r0 < uA);
+            if (mine) {
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)r0 * 256u);
+                if constexpr (HALO) {
+                    const char* b = ((halo_mask >> p) & 1u) ? ht : xt;
+                    dma16_vaddr(b + voff[p], dst);
+                } else {
+                    dma16_saddr(voff[p], xt, dst);
+                }
+            }
+        }
+    };
+
+    __syncthreads();                                      // stream visible to every wave
+    dma_segment(t_begin, false);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // Operand pipeline of a wave, two quads deep.  Quad c uses register set c & 1:
+    //   Xa/Xb  staged operands of quads c, c+1     Wa/Wb  their weights
+    //   Ia/Ib  LDS offsets of quads c+2, c+3 (already fetched)
+    // "Long" body of quad c: after the 4 MFMAs of super-step s have been ISSUED (an MFMA reads its
+    // sources at issue) the same registers are reloaded with super-step s of quad c+2, so every
+    // wave keeps two quads of LDS reads in flight and a wave that runs alone on its SIMD (the
+    // tail of a phase) is not bound by the LDS latency.  The last two quads use the "tail" body.
+    f32x4 Wa, Wb, Xa[4], Xb[4];
+    int4 Ia, Ib;
+#define SGP_LDW(DST, WP, C) DST = *reinterpret_cast<const f32x4*>((WP) + (C) * 256)
+#define SGP_LDI(DST, IP, C) DST = *reinterpret_cast<const int4*>((IP) + (C) * 64)
+#define SGP_LD1(DST, OFF) DST = *reinterpret_cast<const f32x4*>(xmine + (OFF))
+#define SGP_LDX(X, I) SGP_LD1(X[0], (I).x); SGP_LD1(X[1], (I).y); SGP_LD1(X[2], (I).z); SGP_LD1(X[3], (I).w);
+#define SGP_SUPER(W, XV)                                                                        \
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.x, acc0, 0, 0, 0);                          \
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.y, acc1, 0, 0, 0);                          \
+    acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.z, acc2, 0, 0, 0);                          \
+    acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.w, acc3, 0, 0, 0);
+#define SGP_SG(MASK, N) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
+    // tail body: 16 MFMAs, nothing to fetch
+#define SGP_BODY_T(W, X) SGP_SUPER(W.x, X[0]) SGP_SUPER(W.y, X[1]) SGP_SUPER(W.z, X[2]) SGP_SUPER(W.w, X[3])
+    // long body of quad C: MFMAs of C, operand reloads for C+2, then W(C+2) and I(C+4)
+#define SGP_BODY_L(W, X, I, WP, IP, C)                                                          \
+    SGP_SUPER(W.x, X[0]) SGP_LD1(X[0], (I).x);                                                  \
+    SGP_SUPER(W.y, X[1]) SGP_LD1(X[1], (I).y);                                                  \
+    SGP_SUPER(W.z, X[2]) SGP_LD1(X[2], (I).z);                                                  \
+    SGP_SUPER(W.w, X[3]) SGP_LD1(X[3], (I).w);                                                  \
+    SGP_LDW(W, WP, (C) + 2); SGP_LDI(I, IP, (C) + 4);                                           \
+    SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 1)                         \
+    SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 3)
+    // before the barrier (the stream is static): weights of quads 0, 1 and offsets of quads 0, 1
+#define SGP_PRE(WP, IP) SGP_LDI(Ia, IP, 0); SGP_LDI(Ib, IP, 1); SGP_LDW(Wa, WP, 0); SGP_LDW(Wb, WP, 1);
+    // one phase: quads 0 .. NQ-1 of the stream at (WP, IP)
+#define SGP_PHASE(WP, IP, NQ)                                                                   \
+    if ((NQ) > 0 && !(ABL & 2)) {                                                               \
+        SGP_LDX(Xa, Ia)                                                                         \
+        if ((NQ) > 1) { SGP_LDX(Xb, Ib) }                                                       \
+        SGP_LDI(Ia, IP, 2); SGP_LDI(Ib, IP, 3);                                                 \
+        int c = 0;                                                                              \
+        for (; c + 3 < (NQ); c += 2) {                                                          \
+            SGP_BODY_L(Wa, Xa, Ia, WP, IP, c)                                                   \
+            SGP_BODY_L(Wb, Xb, Ib, WP, IP, c + 1)                                               \
+        }                                                                                       \
+        const int left = (NQ) - c;                                                              \
+        if (left == 3) {                                                                        \
+            SGP_BODY_L(Wa, Xa, Ia, WP, IP, c)                                                   \
+            SGP_BODY_T(Wb, Xb)                                                                  \
+            SGP_BODY_T(Wa, Xa)                                                                  \
+        } else if (left == 2) {                                                                 \
+            SGP_BODY_T(Wa, Xa)                                                                  \
+            SGP_BODY_T(Wb, Xb)                                                                  \
+        } else {                                                                                \
+            SGP_BODY_T(Wa, Xa)                                                                  \
+        }                                                                                       \
+    }
+
+    for (int t = t_begin; t < t_end; ++t) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        // ---- phase A: region A holds step t once every wave's pieces have landed
+        // (this wave's pieces of A(t) were retired before the store of step t-1 was issued, so
+        // the barrier does not wait for that store)
+        SGP_PRE(wA, iA)
+        stamp(t, 0);
+        asm volatile("s_barrier" ::: "memory");
+        stamp(t, 1);
+        dma_segment(t, true);
+        stamp(t, 2);
+        SGP_PHASE(wA, iA, nA)
+        // ---- phase B
+        SGP_PRE(wB, iB)
+        stamp(t, 3);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(t, 4);
+        asm volatile("s_barrier" ::: "memory");
+        stamp(t, 5);
+        if (t + 1 < t_end) dma_segment(t + 1, false);
+        SGP_PHASE(wB, iB, nB)
+        stamp(t, 6);
+
+        // sum the 4 column classes; class q keeps row q (see spmm.hip)
+        f32x4 out;
+#define SGP_FOLD(ACC, DST)                                                                       \
+        {                                                                                       \
+            auto p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.x), __float_as_uint(ACC.y), false, false); \
+            auto p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.z), __float_as_uint(ACC.w), false, false); \
+            const float r01 = __uint_as_float(p01[0]) + __uint_as_float(p01[1]);                \
+            const float r23 = __uint_as_float(p23[0]) + __uint_as_float(p23[1]);                \
+            auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r01), __float_as_uint(r23), false, false); \
+            DST = __uint_as_float(h[0]) + __uint_as_float(h[1]);                                \
+        }
+        SGP_FOLD(acc0, out.x) SGP_FOLD(acc1, out.y) SGP_FOLD(acc2, out.z) SGP_FOLD(acc3, out.w)
+#undef SGP_FOLD
+        // retire this wave's DMA of A(t+1) BEFORE the store is issued, so that the next
+        // barrier's vmcnt(0) does not wait for the store that was issued a moment ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(t, 7);
+        // streamed result: nontemporal, so that it does not displace the staged rows other tiles
+        // of this XCD are about to re-read from L2
+        if (my_row >= 0)
+            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(a.Y + (long long)t * a.ybs + (long long)my_row * a.yrs + f_base + li * 4));
+    }
+#undef SGP_PRE
+#undef SGP_PHASE
+#undef SGP_BODY_L
+#undef SGP_BODY_T
+#undef SGP_SG
+#undef SGP_SUPER
+#undef SGP_LDX
+#undef SGP_LD1
+#undef SGP_LDI
+#undef SGP_LDW
+}
+
+int pipe_chunk_cap() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("SGP_SPMM_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }
+    return v;
+}
+
+unsigned pipe_grid(const PipeArgs& a) {
+    if (a.map == 0) return (unsigned)(a.n_tiles * a.n_tchunks);
+    return 8u * (unsigned)(((a.n_tiles + 7) / 8) * a.n_tchunks);
+}
+
+template <bool HALO>
+int launch_pipe(const PipeArgs& a, hipStream_t s) {
+    const size_t lds_bytes = 160 * 1024;
+#ifdef SGP_ABLATION
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
+#define SGP_ABL(V)                                                                                 \
+    if (abl == V) {                                                                                \
+        auto k4 = spmm_pipe<HALO, V>;                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        hipLaunchKernelGGL(k4, dim3(pipe_grid(a), a.feat / 64), dim3(1024), lds_bytes, s, a); \
+        return sgp::check_launch("spmm_pipe");                                                     \
+    }
+    SGP_ABL(1) SGP_ABL(2) SGP_ABL(3) SGP_ABL(4) SGP_ABL(6) SGP_ABL(32)
+#undef SGP_ABL
+#endif
+    auto kern = spmm_pipe<HALO>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return sgp::fail((int)e, "spmm_pipe: LDS opt-in: %s", hipGetErrorString(e));
+    dim3 grid(pipe_grid(a), a.feat / 64);
+    hipLaunchKernelGGL(kern, grid, dim3(1024), lds_bytes, s, a);
+    return sgp::check_launch("spmm_pipe");
+}
+
+}  // namespace
+
+#ifdef SGP_ABLATION
+static unsigned* pipe_dbg_buffer() {
+    static unsigned* p = nullptr;
+    if (!p) { (void)hipMalloc(&p, 4 * 16 * 8 * sizeof(unsigned)); (void)hipMemset(p, 0, 4 * 16 * 8 * sizeof(unsigned)); }
+    return p;
+}
+extern "C" int sgp_spmm_pipe_debug_read(unsigned* host) {
+    return (int)hipMemcpy(host, pipe_dbg_buffer(), 4 * 16 * 8 * sizeof(unsigned), hipMemcpyDeviceToHost);
+}
+#endif
+
+extern "C" {
+
+int32_t sgp_spmm_pipe_max_union(void) { return kPasses * 64; }
+int32_t sgp_spmm_pipe_max_quads(void) { return kMaxQuads; }
+
+int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+                      const int32_t* gptr, const int32_t* gidx, const float* gw,
+                      const int32_t* rowmap,
+                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
+                      const float* X, int64_t xrs, int64_t xbs,
+                      const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
+                      float* Y, int64_t yrs, int64_t ybs,
+                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                      sgp_stream_t stream) {
+    SGP_REQUIRE(uptr && ucol && usplit && gptr && gidx && gw && rowmap && X && Y,
+                "sgp_spmm_pipe_f32: null pointer");
+    SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,
+                "sgp_spmm_pipe_f32: bad size");
+    {
+        // the DMA addresses a staged row as a 32-bit BYTE offset from the step base
+        const long long own = Xh ? n_own : n_cols, far = Xh ? n_cols - n_own : 0;
+        SGP_REQUIRE(n_cols >= 0 && own >= 0 && far >= 0 && own * xrs < (1ll << 30) && far * xhrs < (1ll << 30),
+                    "sgp_spmm_pipe_f32: row offsets exceed 32 bits (use sgp_spmm_csr_f32)");
+    }
+    if (n_rows == 0 || batch == 0 || feat == 0) return 0;
+    if (feat % 64 != 0)
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_pipe_f32: feat=%d is not a multiple of 64", feat);
+    if (max_union > kPasses * 64 || max_tile_quads > kMaxQuads)
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_pipe_f32: tile working set (%d rows, %d quads) exceeds LDS (%d, %d)",
+                         max_union, max_tile_quads, kPasses * 64, kMaxQuads);
+    SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && yrs % 4 == 0 && ybs % 4 == 0 && sgp::aligned16(X) &&
+                sgp::aligned16(Y) && (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh))) &&
+                sgp::aligned16(gidx) && sgp::aligned16(gw),
+                "sgp_spmm_pipe_f32: strides/pointers must be 16-byte aligned");
+    PipeArgs a;
+    a.uptr = uptr; a.ucol = ucol; a.usplit = usplit; a.gptr = gptr; a.gidx = gidx; a.gw = gw;
+    a.rowmap = rowmap;
+    a.n_tiles = n_tiles;
+    a.src = Src2{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
+    a.Y = Y; a.yrs = yrs; a.ybs = ybs;
+    a.n_rows = n_rows; a.batch = batch; a.feat = feat;
+    // Time chunk per workgroup: long enough to amortise the per-tile setup, short enough that
+    // neighbouring tiles (which share source rows through L2 / Infinity Cache) stay in step.
+    const int nft = feat / 64;
+    long long want = (long long)batch * n_tiles * nft / 4096;
+    int tc = (int)(want < 16 ? 16 : (want > pipe_chunk_cap() ? pipe_chunk_cap() : want));
+    if (tc > batch) tc = batch;
+    a.t_chunk = tc;
+    a.n_tchunks = (batch + tc - 1) / tc;
+    a.dbg = nullptr;
+    { static int m = -1; if (m < 0) { const char* e = getenv("SGP_PIPE_MAP"); m = e ? atoi(e) : 0; } a.map = m; }
+#ifdef SGP_ABLATION
+    a.dbg = pipe_dbg_buffer();
+#endif
+    hipStream_t s = (hipStream_t)stream;
+    return Xh ? launch_pipe<true>(a, s) : launch_pipe<false>(a, s);
+}
+
+}  // extern "C"

@@ -168,17 +168,23 @@ class ShiftOperator:
         if plan is not None and halo is not None and \
                 halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 31:
             plan = None                      # tiled kernels use 32-bit row offsets
-        if force in ("tiled", "mfma") and plan is None:
+        if force in ("tiled", "mfma", "pipe") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
         if force == "mfma" and (plan is None or plan.gw is None):
             raise NotImplementedError("no row-group stream for this plan")
         # matrix-core row groups pay off when 4-row groups share most columns (k-NN graphs)
         use_mfma = plan is not None and plan.gw is not None and \
-            (force == "mfma" or (force is None and plan.group_fill >= 0.5 and
+            (force in ("mfma", "pipe") or (force is None and plan.group_fill >= 0.5 and
                                  plan.max_tile_quads <= hip.load().sgp_spmm_mfma_max_quads()))
-        self.last_kernel = "spmm_mfma" if use_mfma else ("spmm_tiled" if plan is not None
-                                                         else "spmm_csr_rows")
-        if use_mfma:
+        use_pipe = use_mfma and plan.pipe is not None and force in (None, "pipe") and \
+            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
+        if force == "pipe" and not use_pipe:
+            raise NotImplementedError("no two-phase stream for this plan")
+        self.last_kernel = "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
+            "spmm_tiled" if plan is not None else "spmm_csr_rows")
+        if use_pipe:
+            hip.spmm_pipe(plan, x, y, halo, self.num_nodes)
+        elif use_mfma:
             hip.spmm_mfma(plan, x, y, halo, self.num_nodes)
         elif plan is not None:
             hip.spmm_tiled(plan, x, y, halo, self.num_nodes)
@@ -228,14 +234,17 @@ class TilePlan:
     gw: Optional[torch.Tensor] = None       # float32 [n_quads, 4 classes, 4 rows, 4]
     max_tile_quads: int = 0
     rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
+    pipe: Optional[dict] = None             # two-phase stream of sgp_spmm_pipe_f32 (build_phase_stream)
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
+        pipe = None if self.pipe is None else {
+            k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.pipe.items()}
         return TilePlan(self.trow.to(device), self.uptr.to(device), self.ucol.to(device),
                         self.erow.to(device), self.ecol.to(device), self.eval.to(device),
                         self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
                         self.max_row_edges, mv(self.gptr), self.group_fill,
-                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap))
+                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap), pipe)
 
 
 def tile_unions(rowptr, col, trow):
@@ -396,6 +405,166 @@ def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
     return gptr.astype(np.int32), fill, gidx, gw, rowmap
 
 
+def choose_segment_split(n_tiles, g_s, lc, counts):
+    """Cut point ``uA`` (a multiple of 4) of every tile's distinct-column list for the two-phase
+    kernel: columns < uA are staged in region A, the rest in region B, and every group walks
+    ceil(nA / 16) + ceil(nB / 16) quads.  Picks, per tile, the cut that minimises the sum over
+    the two phases of the busiest SIMD class (slot % 4) in quads.  ``g_s, lc`` = (group, local
+    column) of every distinct (group, column) entry, ``counts`` = entries per group."""
+    G = GROUPS_PER_TILE
+    # columns are < 65536; histogram of entries per (group, column // 4)
+    width = int(lc.max(initial=0)) // 4 + 2
+    hist = np.zeros((n_tiles * G, width), dtype=np.int32)
+    np.add.at(hist, (g_s, lc // 4), 1)
+    below = np.zeros((n_tiles * G, width + 1), dtype=np.int32)   # below[g, j] = #cols < 4 j
+    np.cumsum(hist, axis=1, out=below[:, 1:])
+    tot = counts.astype(np.int32)[:, None]
+    qa = (below + 15) // 16
+    qb = (tot - below + 15) // 16
+    # SIMD class of wave slot s is s % 4 (speed assumption only)
+    qa_c = qa.reshape(n_tiles, G // 4, 4, width + 1).sum(1)
+    qb_c = qb.reshape(n_tiles, G // 4, 4, width + 1).sum(1)
+    ma, mb = qa_c.max(1), qb_c.max(1)                             # [n_tiles, width + 1]
+    cost = ma + mb
+    # each phase must be long enough to hide the DMA of the other segment: keep the shorter
+    # phase at >= 40 % of the step where possible, then the cheapest cut, then the most even
+    lopsided = np.minimum(ma, mb) * 5 < cost * 2
+    score = lopsided.astype(np.int64) * (1 << 40) + cost.astype(np.int64) * 4096 + \
+        np.minimum(np.abs(ma - mb), 4095)
+    j = np.argmin(score, axis=1)
+    jg = np.repeat(j, G)
+    rows = np.arange(n_tiles * G)
+    return (4 * j).astype(np.int32), cost[np.arange(n_tiles), j], \
+        qa[rows, jg].reshape(n_tiles, G), qb[rows, jg].reshape(n_tiles, G)
+
+
+def place_groups_two_phase(qa, qb):
+    """Wave slot of every group (per tile) so that the four SIMD classes (slot % 4) carry about
+    the same number of quads in BOTH phases: longest group first, each into the class (with a
+    free slot) that keeps max_A + max_B smallest."""
+    n_tiles, G = qa.shape
+    per_class = G // 4
+    order = np.argsort(-(qa + qb), axis=1, kind="stable")
+    new_slot = np.empty_like(order)
+    for k in range(n_tiles):
+        la = np.zeros(4, dtype=np.int64)
+        lb = np.zeros(4, dtype=np.int64)
+        used = np.zeros(4, dtype=np.int64)
+        for g in order[k]:
+            a, b = qa[k, g], qb[k, g]
+            best, best_cost = -1, None
+            for c in range(4):
+                if used[c] >= per_class:
+                    continue
+                ca = max(la.max(), la[c] + a) + max(lb.max(), lb[c] + b)
+                cst = (ca, la[c] + lb[c])
+                if best_cost is None or cst < best_cost:
+                    best, best_cost = c, cst
+            new_slot[k, g] = best + 4 * used[best]
+            la[best] += a
+            lb[best] += b
+            used[best] += 1
+    return new_slot
+
+
+def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=None, rebalance=True,
+                       mode="parity"):
+    """Row-group stream of ``sgp_spmm_pipe_f32`` (include/sgp_amd.h): as ``build_group_stream`` but
+    every tile's distinct-column list is cut into two segments A | B that the kernel stages
+    alternately, and every group's quads are stored A-part first: ``gptr[2 g] .. gptr[2 g + 1]`` =
+    quads that only touch segment A, ``gptr[2 g + 1] .. gptr[2 g + 2]`` = quads of segment B.
+
+    ``mode="parity"``: even positions of the sorted list -> A, odd -> B, so every group finds
+    about half of its columns in either segment and all waves have the same amount of work in
+    both phases.  ``mode="sorted"``: A = the first ``usplit`` columns (groups at the rim of a
+    tile then work in one phase only).  Returns the permuted column list (``uptr``/``ucol``,
+    segment A padded to a multiple of 4 rows) along with the stream."""
+    n_tiles = len(trow) - 1
+    n_rows = int(trow[-1])
+    tile_of_row = np.repeat(np.arange(n_tiles, dtype=np.int64), np.diff(trow))
+    in_tile = np.arange(n_rows, dtype=np.int64) - trow[tile_of_row] if slot_of_row is None \
+        else slot_of_row
+    assert in_tile.max(initial=0) < GROUP_ROWS * GROUPS_PER_TILE
+    group_of_row = tile_of_row * GROUPS_PER_TILE + in_tile // GROUP_ROWS
+    slot_in_group = in_tile % GROUP_ROWS
+    n_groups = n_tiles * GROUPS_PER_TILE
+    g_e = group_of_row[row_of_edge]
+    key = g_e * 65536 + lcol
+    uniq, inv = np.unique(key, return_inverse=True)          # one entry per (group, column)
+    g_s = uniq >> 16
+    lc = uniq & 0xffff
+    t_s = g_s // GROUPS_PER_TILE
+    counts = np.bincount(g_s, minlength=n_groups)
+    uptr = np.asarray(uptr, dtype=np.int64)
+    U = np.diff(uptr)
+    if mode == "parity":
+        usplit = ((U + 1) // 2 + 3) // 4 * 4                  # rows of region A (padded)
+        seg = lc & 1
+        stage_slot = np.where(seg == 0, lc >> 1, usplit[t_s] + (lc >> 1))
+        upad = usplit + U // 2
+        qa = (np.bincount(g_s, weights=(seg == 0), minlength=n_groups).astype(np.int64) + 15) // 16
+        qb = (np.bincount(g_s, weights=(seg == 1), minlength=n_groups).astype(np.int64) + 15) // 16
+        qa, qb = qa.reshape(n_tiles, -1), qb.reshape(n_tiles, -1)
+    else:
+        usplit, _, qa, qb = choose_segment_split(n_tiles, g_s, lc, counts)
+        usplit = usplit.astype(np.int64)
+        seg = (lc >= usplit[t_s]).astype(np.int64)
+        stage_slot = lc
+        upad = np.maximum(U, usplit)
+    if rebalance:
+        # re-deal the groups over the wave slots for the two-phase loads
+        new_slot = place_groups_two_phase(qa, qb)
+        t_of_g = np.arange(n_groups) // GROUPS_PER_TILE
+        new_group = t_of_g * GROUPS_PER_TILE + new_slot.reshape(-1)
+        in_tile = (new_group[group_of_row] % GROUPS_PER_TILE) * GROUP_ROWS + slot_in_group
+        return build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, in_tile,
+                                  rebalance=False, mode=mode)
+    # permuted / padded column list (padding repeats the tile's first column)
+    uptr2 = np.zeros(n_tiles + 1, dtype=np.int64)
+    uptr2[1:] = np.cumsum(upad)
+    ucol = np.asarray(ucol)
+    first_col = ucol[np.minimum(uptr[:-1], max(len(ucol) - 1, 0))] if len(ucol) else np.zeros(n_tiles, np.int32)
+    ucol2 = np.repeat(first_col, upad).astype(np.int32)
+    tile_of_u = np.repeat(np.arange(n_tiles, dtype=np.int64), U)
+    l_of_u = np.arange(len(ucol), dtype=np.int64) - uptr[tile_of_u]
+    if mode == "parity":
+        s_of_u = np.where((l_of_u & 1) == 0, l_of_u >> 1, usplit[tile_of_u] + (l_of_u >> 1))
+    else:
+        s_of_u = l_of_u
+    ucol2[uptr2[tile_of_u] + s_of_u] = ucol
+    # entries ordered by (half-group, staged slot)
+    h_s = 2 * g_s + seg
+    order = np.argsort(h_s * 65536 + stage_slot, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    h_s, stage_slot = h_s[order], stage_slot[order]
+    inv = rank[inv]
+    hcounts = np.bincount(h_s, minlength=2 * n_groups)
+    quads = (hcounts + 15) // 16
+    gptr = np.zeros(2 * n_groups + 1, dtype=np.int64)
+    gptr[1:] = np.cumsum(quads)
+    first = np.zeros(2 * n_groups + 1, dtype=np.int64)
+    first[1:] = np.cumsum(hcounts)
+    p = np.arange(h_s.size, dtype=np.int64) - first[h_s]     # position in the half-group's list
+    quad = gptr[h_s] + p // 16
+    sup, cls = (p // 4) % 4, p % 4
+    n_quads = int(gptr[-1])
+    gidx = np.zeros((n_quads, 4, 4), dtype=np.int32)
+    gidx[quad, cls, sup] = (stage_slot * 256).astype(np.int32)
+    gw = np.zeros((n_quads, 4, GROUP_ROWS, 4), dtype=np.float32)
+    gw[quad[inv], cls[inv], slot_in_group[row_of_edge], sup[inv]] = val
+    fill = float(lcol.size) / max(1, n_quads * 16 * GROUP_ROWS)
+    max_tile_quads = int(np.diff(gptr[::2 * GROUPS_PER_TILE]).max()) if n_tiles else 0
+    rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)
+    rowmap[tile_of_row * (GROUP_ROWS * GROUPS_PER_TILE) + in_tile] = np.arange(n_rows, dtype=np.int32)
+    hq = np.diff(gptr).reshape(n_tiles, GROUPS_PER_TILE // 4, 4, 2).sum(1)     # [tile, class, phase]
+    phase_cost = hq.max(1).sum(1)
+    return dict(usplit=usplit.astype(np.int32), uptr=uptr2.astype(np.int32), ucol=ucol2,
+                gptr=gptr.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
+                max_tile_quads=max_tile_quads, max_union=int(upad.max(initial=0)),
+                phase_cost=phase_cost, rowmap=rowmap)
+
+
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
                     candidates=(64, 32, 16), cluster=True) -> Optional[TilePlan]:
     """Tallest tiling whose per-tile working set fits the LDS stage, or None when the
@@ -444,5 +613,12 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
             plan.gidx, plan.gw = torch.from_numpy(gidx), torch.from_numpy(gw)
             plan.rowmap = torch.from_numpy(rowmap)
             plan.max_tile_quads = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
+            ps = build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, np.asarray(val), slots)
+            plan.pipe = dict(usplit=torch.from_numpy(ps["usplit"]), gptr=torch.from_numpy(ps["gptr"]),
+                             uptr=torch.from_numpy(ps["uptr"]), ucol=torch.from_numpy(ps["ucol"]),
+                             max_union=ps["max_union"],
+                             gidx=torch.from_numpy(ps["gidx"]), gw=torch.from_numpy(ps["gw"]),
+                             rowmap=torch.from_numpy(ps["rowmap"]), fill=ps["fill"],
+                             max_tile_quads=ps["max_tile_quads"])
         return plan
     return None

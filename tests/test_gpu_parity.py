@@ -73,7 +73,7 @@ def test_spmm_csr_strided_slots_in_place():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     buf = torch.randn(t, n, p * d, device="cuda")
     ref = buf.clone()
-    for force in ("csr", "tiled", "mfma"):
+    for force in ("csr", "tiled", "mfma", "pipe"):
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
@@ -93,7 +93,7 @@ def test_spmm_tiled_knn(n, k, feat):
     plan = op.tile_plan(feat, torch.device("cuda"))
     assert plan is not None
     x = torch.randn(5, n, feat)
-    for force in ("tiled", "mfma"):
+    for force in ("tiled", "mfma", "pipe"):
         y = torch.full((5, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -112,7 +112,7 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     op = graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n)
     assert op.tile_plan(feat, torch.device("cuda")) is not None
     x = torch.randn(t, n, feat)
-    for force in ("tiled", "mfma"):
+    for force in ("tiled", "mfma", "pipe"):
         y = torch.full((t, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -123,7 +123,7 @@ def test_spmm_traffic_graph_small_n_long_t():
     ei, ew = synthetic.sparse_traffic_graph(325, 2369, seed=2)
     op = graph.ShiftOperator.from_edges(ei, ew, 325)
     x = torch.randn(600, 325, 128)
-    for force in ("csr", "tiled", "mfma"):
+    for force in ("csr", "tiled", "mfma", "pipe"):
         y = torch.empty(600, 325, 128, device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -414,7 +414,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("mfma", "tiled", "csr"):
+    for force in ("pipe", "mfma", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity
@@ -446,7 +446,7 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
         assert blk.n_halo > 0
         xo = x[:, blk.lo:blk.hi].cuda().contiguous()
         recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()      # [rows, T, D]
-        for force in ("csr", "tiled", "mfma"):
+        for force in ("csr", "tiled", "mfma", "pipe"):
             y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
             blk.op.propagate(xo, y, force=force, halo=recv.permute(1, 0, 2))
             close(y, ref[:, blk.lo:blk.hi])

@@ -132,10 +132,12 @@ int32_t sgp_spmm_mfma_max_quads(void);
  * the segments: gptr[2 (16 k + g)] .. gptr[2 (16 k + g) + 1] = quads on segment A,
  * .. gptr[2 (16 k + g) + 2] = quads on segment B.  Per time step the kernel refills one segment
  * of the LDS stage by LDS-DMA (global_load_lds_dwordx4) while the matrix cores consume the other.
- * gidx / gw / rowmap as for sgp_spmm_mfma_f32.  Limits: sgp_spmm_pipe_max_union() staged rows
+ * gsup[2 (16 k + g) + s] = ceil(columns of that range / 4): the kernel skips the padding of a
+ * range's last quad in units of one super-step.  uptr / ucol list segment A first (padded to a
+ * multiple of 4 entries), then segment B.  gidx / gw / rowmap as for sgp_spmm_mfma_f32.  Limits: sgp_spmm_pipe_max_union() staged rows
  * per tile, sgp_spmm_pipe_max_quads() quads per tile. */
 int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
-                      const int32_t* gptr, const int32_t* gidx, const float* gw,
+                      const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
                       const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 using sgp::f32x4;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -31,6 +32,7 @@ struct Src2 {
 struct PipeArgs {
     const int* uptr; const int* ucol; const int* usplit;
     const int* gptr;                       // [32 * n_tiles + 1]: (A, B) quad ranges per group
+    const int* gsup;                       // [32 * n_tiles]: super-steps (columns / 4, rounded up) per range
     const int* gidx; const float* gw; const int* rowmap;
     int n_tiles;
     Src2 src;
@@ -53,17 +55,15 @@ constexpr int kMaxQuads = (160 * 1024 - kStageBytes - kSlackBytes) / kQuadBytes;
 // (wave-uniform byte address, via M0).  Issued from asm so that hipcc's s_waitcnt bookkeeping does
 // not know about it: the compiler would otherwise drain vmcnt(0) in front of every ds_read that
 // follows.  Completion is counted by hand (s_waitcnt vmcnt(0) before the phase barrier).
+// M0 is written here and nowhere else in this kernel (the compiler has no use for it: no
+// LDS-DMA builtin, no movrel, no GWS), so it is neither saved nor restored.
 __device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, unsigned lds_off) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
 __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(vaddr), "s"(lds_off) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                 :: "v"(vaddr), "s"(lds_off) : "memory");
 }
 
 template <bool HALO, int ABL = 0>
@@ -144,11 +144,22 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     const int gB = __builtin_amdgcn_readfirstlane(a.gptr[grp + 1]) - tile_q0;
     const int gE = __builtin_amdgcn_readfirstlane(a.gptr[grp + 2]) - tile_q0;
     const int nA = gB - gA, nB = gE - gB;
+    // super-steps of the LAST quad of either range (1..4): the padding of a range is skipped in
+    // units of 4 columns instead of 16
+    const int lastA = __builtin_amdgcn_readfirstlane(a.gsup[grp]) - 4 * (nA - 1);
+    const int lastB = __builtin_amdgcn_readfirstlane(a.gsup[grp + 1]) - 4 * (nB - 1);
     const int my_row = a.rowmap[tile * 64 + wave * 4 + q];   // output row of class q (-1: none)
-    const char* wA = wlds + gA * 256 + (q * 4 + (lane & 3)) * 16;
-    const char* iA = ilds + gA * 64 + q * 16;
-    const char* wB = wA + nA * 256;
-    const char* iB = iA + nA * 64;
+    // per-lane LDS byte addresses of the wave's stream (quad 0 of either range).  They are kept
+    // as opaque integers: a read is "address register + small immediate", the loop advances the
+    // registers -- otherwise the compiler rebuilds `lds + 0x1c000 + ...` with a VALU add per read.
+    typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
+    typedef const __attribute__((address_space(3))) i32x4* lds_i4_t;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+    unsigned wA = lds0 + kStageBytes + gA * 256 + (q * 4 + (lane & 3)) * 16;
+    unsigned iA = lds0 + kStageBytes + tile_quads * 256 + gA * 64 + q * 16;
+    unsigned wB = wA + nA * 256;
+    unsigned iB = iA + nA * 64;
+    asm volatile("" : "+v"(wA), "+v"(iA), "+v"(wB), "+v"(iB));
     const char* xmine = lds + li * 16;
     // debug timeline (ABL & 32): workgroup `dbg[0]` records s_memtime at 8 points of 4 steps
     auto stamp = [&](int t, int point) {
@@ -162,12 +173,16 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     };
 
     // DMA of one segment of step t: wave w moves staged rows 64 p + 4 w .. + 3 (one 1-KiB piece)
-    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    auto dma_segment = [&](int t, bool seg_b) {
+    const unsigned lds_base = lds0;
+    const char* x_step = reinterpret_cast<const char*>(a.src.x + (long long)t_begin * a.src.xbs);
+    const char* h_step = reinterpret_cast<const char*>(a.src.xh + (long long)t_begin * a.src.xhbs);
+    const long long x_inc = a.src.xbs * 4, h_inc = a.src.xhbs * 4;
+    const char* const x_step0 = x_step;
+    const char* const h_step0 = h_step;
+    // (xt, ht) = base of the step whose rows are fetched
+    auto dma_segment = [&](const char* xt, const char* ht, bool seg_b) {
         if constexpr (ABL & 1) return;                    // ablation: no staging traffic
-        if constexpr (ABL & 4) t = t_begin;               // ablation: staging hits L2
-        const char* xt = reinterpret_cast<const char*>(a.src.x + (long long)t * a.src.xbs);
-        const char* ht = reinterpret_cast<const char*>(a.src.xh + (long long)t * a.src.xhbs);
+        if constexpr (ABL & 4) { xt = x_step0; ht = h_step0; }   // ablation: staging hits L2
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
             const int r0 = p * 64 + wave * 4;             // scalar
@@ -183,9 +198,8 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
             }
         }
     };
-
     __syncthreads();                                      // stream visible to every wave
-    dma_segment(t_begin, false);
+    dma_segment(x_step, h_step, false);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // Operand pipeline of a wave, two quads deep.  Quad c uses register set c & 1:
@@ -196,9 +210,9 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     // wave keeps two quads of LDS reads in flight and a wave that runs alone on its SIMD (the
     // tail of a phase) is not bound by the LDS latency.  The last two quads use the "tail" body.
     f32x4 Wa, Wb, Xa[4], Xb[4];
-    int4 Ia, Ib;
-#define SGP_LDW(DST, WP, C) DST = *reinterpret_cast<const f32x4*>((WP) + (C) * 256)
-#define SGP_LDI(DST, IP, C) DST = *reinterpret_cast<const int4*>((IP) + (C) * 64)
+    i32x4 Ia, Ib;
+#define SGP_LDW(DST, WP, C) DST = *(lds_f4_t)((WP) + (C) * 256)
+#define SGP_LDI(DST, IP, C) DST = *(lds_i4_t)((IP) + (C) * 64)
 #define SGP_LD1(DST, OFF) DST = *reinterpret_cast<const f32x4*>(xmine + (OFF))
 #define SGP_LDX(X, I) SGP_LD1(X[0], (I).x); SGP_LD1(X[1], (I).y); SGP_LD1(X[2], (I).z); SGP_LD1(X[3], (I).w);
 #define SGP_SUPER(W, XV)                                                                        \
@@ -210,7 +224,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     // tail body: 16 MFMAs, nothing to fetch
 #define SGP_BODY_T(W, X) SGP_SUPER(W.x, X[0]) SGP_SUPER(W.y, X[1]) SGP_SUPER(W.z, X[2]) SGP_SUPER(W.w, X[3])
     // long body of quad C: MFMAs of C, operand reloads for C+2, then W(C+2) and I(C+4)
-#define SGP_BODY_L(W, X, I, WP, IP, C)                                                          \
+#define SGP_BODY_L(W, X, I, WP, IP, C)  /* C = 0 or 1: quad relative to the running pointers */ \
     SGP_SUPER(W.x, X[0]) SGP_LD1(X[0], (I).x);                                                  \
     SGP_SUPER(W.y, X[1]) SGP_LD1(X[1], (I).y);                                                  \
     SGP_SUPER(W.z, X[2]) SGP_LD1(X[2], (I).z);                                                  \
@@ -218,32 +232,42 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     SGP_LDW(W, WP, (C) + 2); SGP_LDI(I, IP, (C) + 4);                                           \
     SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 1)                         \
     SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 3)
+    // last quad of a range: only its first NS super-steps carry columns
+#define SGP_BODY_E(W, X, NS)                                                                    \
+    SGP_SUPER(W.x, X[0])                                                                        \
+    if ((NS) > 1) { SGP_SUPER(W.y, X[1])                                                        \
+        if ((NS) > 2) { SGP_SUPER(W.z, X[2])                                                    \
+            if ((NS) > 3) { SGP_SUPER(W.w, X[3]) } } }
     // before the barrier (the stream is static): weights of quads 0, 1 and offsets of quads 0, 1
 #define SGP_PRE(WP, IP) SGP_LDI(Ia, IP, 0); SGP_LDI(Ib, IP, 1); SGP_LDW(Wa, WP, 0); SGP_LDW(Wb, WP, 1);
-    // one phase: quads 0 .. NQ-1 of the stream at (WP, IP)
-#define SGP_PHASE(WP, IP, NQ)                                                                   \
+    // one phase: quads 0 .. NQ-1 of the stream at (WP, IP), the last one NS super-steps long
+#define SGP_PHASE(WP0, IP0, NQ, NS)                                                             \
     if ((NQ) > 0 && !(ABL & 2)) {                                                               \
+        unsigned wq = (WP0), iq = (IP0);                                                        \
         SGP_LDX(Xa, Ia)                                                                         \
         if ((NQ) > 1) { SGP_LDX(Xb, Ib) }                                                       \
-        SGP_LDI(Ia, IP, 2); SGP_LDI(Ib, IP, 3);                                                 \
+        SGP_LDI(Ia, iq, 2); SGP_LDI(Ib, iq, 3);                                                 \
         int c = 0;                                                                              \
         for (; c + 3 < (NQ); c += 2) {                                                          \
-            SGP_BODY_L(Wa, Xa, Ia, WP, IP, c)                                                   \
-            SGP_BODY_L(Wb, Xb, Ib, WP, IP, c + 1)                                               \
+            SGP_BODY_L(Wa, Xa, Ia, wq, iq, 0)                                                   \
+            SGP_BODY_L(Wb, Xb, Ib, wq, iq, 1)                                                   \
+            wq += 512; iq += 128;                                                               \
+            asm volatile("" : "+v"(wq), "+v"(iq));                                              \
         }                                                                                       \
         const int left = (NQ) - c;                                                              \
         if (left == 3) {                                                                        \
-            SGP_BODY_L(Wa, Xa, Ia, WP, IP, c)                                                   \
+            SGP_BODY_L(Wa, Xa, Ia, wq, iq, 0)                                                   \
             SGP_BODY_T(Wb, Xb)                                                                  \
-            SGP_BODY_T(Wa, Xa)                                                                  \
+            SGP_BODY_E(Wa, Xa, NS)                                                              \
         } else if (left == 2) {                                                                 \
             SGP_BODY_T(Wa, Xa)                                                                  \
-            SGP_BODY_T(Wb, Xb)                                                                  \
+            SGP_BODY_E(Wb, Xb, NS)                                                              \
         } else {                                                                                \
-            SGP_BODY_T(Wa, Xa)                                                                  \
+            SGP_BODY_E(Wa, Xa, NS)                                                              \
         }                                                                                       \
     }
 
+    float* y_row = a.Y + (long long)t_begin * a.ybs + (long long)(my_row < 0 ? 0 : my_row) * a.yrs + f_base + li * 4;
     for (int t = t_begin; t < t_end; ++t) {
         f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
         // ---- phase A: region A holds step t once every wave's pieces have landed
@@ -253,9 +277,15 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         stamp(t, 0);
         asm volatile("s_barrier" ::: "memory");
         stamp(t, 1);
-        dma_segment(t, true);
+        // the refill of the other region is issued first by the younger half of the waves (the
+        // hardware serves the oldest wave of a SIMD first, they would wait for the matrix pipe
+        // anyway) and after their quads by the older half: an LDS-DMA piece costs its wave
+        // 150+ cycles of issue, which must not idle the matrix pipe at the start of the phase
+        const bool dma_first = wave >= 8;
+        if (dma_first) dma_segment(x_step, h_step, true);
         stamp(t, 2);
-        SGP_PHASE(wA, iA, nA)
+        SGP_PHASE(wA, iA, nA, lastA)
+        if (!dma_first) dma_segment(x_step, h_step, true);
         // ---- phase B
         SGP_PRE(wB, iB)
         stamp(t, 3);
@@ -263,8 +293,9 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         stamp(t, 4);
         asm volatile("s_barrier" ::: "memory");
         stamp(t, 5);
-        if (t + 1 < t_end) dma_segment(t + 1, false);
-        SGP_PHASE(wB, iB, nB)
+        if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, false);
+        SGP_PHASE(wB, iB, nB, lastB)
+        if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, false);
         stamp(t, 6);
 
         // sum the 4 column classes; class q keeps row q (see spmm.hip)
@@ -287,12 +318,15 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         // streamed result: nontemporal, so that it does not displace the staged rows other tiles
         // of this XCD are about to re-read from L2
         if (my_row >= 0)
-            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(a.Y + (long long)t * a.ybs + (long long)my_row * a.yrs + f_base + li * 4));
+            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(y_row));
+        y_row += a.ybs;
+        x_step += x_inc; h_step += h_inc;
     }
 #undef SGP_PRE
 #undef SGP_PHASE
 #undef SGP_BODY_L
 #undef SGP_BODY_T
+#undef SGP_BODY_E
 #undef SGP_SG
 #undef SGP_SUPER
 #undef SGP_LDX
@@ -325,7 +359,7 @@ int launch_pipe(const PipeArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, dim3(pipe_grid(a), a.feat / 64), dim3(1024), lds_bytes, s, a); \
         return sgp::check_launch("spmm_pipe");                                                     \
     }
-    SGP_ABL(1) SGP_ABL(2) SGP_ABL(3) SGP_ABL(4) SGP_ABL(6) SGP_ABL(32)
+    SGP_ABL(1) SGP_ABL(2) SGP_ABL(3) SGP_ABL(4) SGP_ABL(6) SGP_ABL(32) SGP_ABL(33) SGP_ABL(35)
 #undef SGP_ABL
 #endif
     auto kern = spmm_pipe<HALO>;
@@ -356,7 +390,7 @@ int32_t sgp_spmm_pipe_max_union(void) { return kPasses * 64; }
 int32_t sgp_spmm_pipe_max_quads(void) { return kMaxQuads; }
 
 int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
-                      const int32_t* gptr, const int32_t* gidx, const float* gw,
+                      const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
                       const int32_t* rowmap,
                       int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
                       const float* X, int64_t xrs, int64_t xbs,
@@ -364,7 +398,7 @@ int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* u
                       float* Y, int64_t yrs, int64_t ybs,
                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                       sgp_stream_t stream) {
-    SGP_REQUIRE(uptr && ucol && usplit && gptr && gidx && gw && rowmap && X && Y,
+    SGP_REQUIRE(uptr && ucol && usplit && gptr && gsup && gidx && gw && rowmap && X && Y,
                 "sgp_spmm_pipe_f32: null pointer");
     SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,
                 "sgp_spmm_pipe_f32: bad size");
@@ -385,7 +419,7 @@ int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* u
                 sgp::aligned16(gidx) && sgp::aligned16(gw),
                 "sgp_spmm_pipe_f32: strides/pointers must be 16-byte aligned");
     PipeArgs a;
-    a.uptr = uptr; a.ucol = ucol; a.usplit = usplit; a.gptr = gptr; a.gidx = gidx; a.gw = gw;
+    a.uptr = uptr; a.ucol = ucol; a.usplit = usplit; a.gptr = gptr; a.gsup = gsup; a.gidx = gidx; a.gw = gw;
     a.rowmap = rowmap;
     a.n_tiles = n_tiles;
     a.src = Src2{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};

@@ -541,6 +541,7 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
     inv = rank[inv]
     hcounts = np.bincount(h_s, minlength=2 * n_groups)
     quads = (hcounts + 15) // 16
+    gsup = (hcounts + 3) // 4                                 # super-steps actually occupied
     gptr = np.zeros(2 * n_groups + 1, dtype=np.int64)
     gptr[1:] = np.cumsum(quads)
     first = np.zeros(2 * n_groups + 1, dtype=np.int64)
@@ -553,14 +554,14 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
     gidx[quad, cls, sup] = (stage_slot * 256).astype(np.int32)
     gw = np.zeros((n_quads, 4, GROUP_ROWS, 4), dtype=np.float32)
     gw[quad[inv], cls[inv], slot_in_group[row_of_edge], sup[inv]] = val
-    fill = float(lcol.size) / max(1, n_quads * 16 * GROUP_ROWS)
+    fill = float(lcol.size) / max(1, int(gsup.sum()) * 4 * GROUP_ROWS)
     max_tile_quads = int(np.diff(gptr[::2 * GROUPS_PER_TILE]).max()) if n_tiles else 0
     rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)
     rowmap[tile_of_row * (GROUP_ROWS * GROUPS_PER_TILE) + in_tile] = np.arange(n_rows, dtype=np.int32)
     hq = np.diff(gptr).reshape(n_tiles, GROUPS_PER_TILE // 4, 4, 2).sum(1)     # [tile, class, phase]
     phase_cost = hq.max(1).sum(1)
     return dict(usplit=usplit.astype(np.int32), uptr=uptr2.astype(np.int32), ucol=ucol2,
-                gptr=gptr.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
+                gptr=gptr.astype(np.int32), gsup=gsup.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
                 max_tile_quads=max_tile_quads, max_union=int(upad.max(initial=0)),
                 phase_cost=phase_cost, rowmap=rowmap)
 
@@ -615,6 +616,7 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
             plan.max_tile_quads = int(np.diff(gptr[::GROUPS_PER_TILE].astype(np.int64)).max())
             ps = build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, np.asarray(val), slots)
             plan.pipe = dict(usplit=torch.from_numpy(ps["usplit"]), gptr=torch.from_numpy(ps["gptr"]),
+                             gsup=torch.from_numpy(ps["gsup"]),
                              uptr=torch.from_numpy(ps["uptr"]), ucol=torch.from_numpy(ps["ucol"]),
                              max_union=ps["max_union"],
                              gidx=torch.from_numpy(ps["gidx"]), gw=torch.from_numpy(ps["gw"]),

@@ -40,7 +40,7 @@ SIGNATURES = {
                                          c_p, c_i64, c_i64, c_i32,
                                          c_p, c_i64, c_i64,
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_pipe_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+    "sgp_spmm_pipe_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                          c_i32, c_i32, c_i32,
                                          c_p, c_i64, c_i64,
                                          c_p, c_i64, c_i64, c_i32,
@@ -228,7 +228,8 @@ def spmm_pipe(plan, x, y, halo=None, n_own=None):
     ps = plan.pipe
     _check(lib.sgp_spmm_pipe_f32(
         ps["uptr"].data_ptr(), ps["ucol"].data_ptr(), ps["usplit"].data_ptr(),
-        ps["gptr"].data_ptr(), ps["gidx"].data_ptr(), ps["gw"].data_ptr(), ps["rowmap"].data_ptr(),
+        ps["gptr"].data_ptr(), ps["gsup"].data_ptr(), ps["gidx"].data_ptr(), ps["gw"].data_ptr(),
+        ps["rowmap"].data_ptr(),
         plan.n_tiles, ps["max_union"], ps["max_tile_quads"],
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),

@@ -1,7 +1,7 @@
 """Debug: per-wave s_memtime timeline of one workgroup of spmm_pipe (ablation build, SGP_PIPE_ABL=32)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SGP_PIPE_ABL"] = "32"
+os.environ.setdefault("SGP_PIPE_ABL", "32")
 import numpy as np, torch
 from sgp_amd import graph, hip, synthetic
 N, T, D = 100000, 64, 64

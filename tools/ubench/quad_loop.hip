@@ -30,7 +30,8 @@ __global__ __launch_bounds__(1024) void quad_loop(float* sink, unsigned long lon
 #define LDI(DST, C) if (!(VARIANT & 4)) DST = *reinterpret_cast<const int4*>(IP + ((C) & 15) * 64)
 #define LD1(DST, OFF) if (!(VARIANT & 2)) DST = *reinterpret_cast<const f32x4*>(xmine + (OFF))
 #define LDX(X, I) LD1(X[0], (I).x); LD1(X[1], (I).y); LD1(X[2], (I).z); LD1(X[3], (I).w);
-#define SUPER(W, XV) if (!(VARIANT & 1)) {                                       \
+#define MFA(ACC, W, XS) asm("v_mfma_f32_4x4x1_16b_f32 %0, %1, %2, %0" : "+a"(ACC) : "v"(W), "v"(XS));
+#define SUPER(W, XV) if (VARIANT & 48) { MFA(acc0, W, XV.x) MFA(acc1, W, XV.y) MFA(acc2, W, XV.z) MFA(acc3, W, XV.w) } else if (!(VARIANT & 1)) { \
     acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.x, acc0, 0, 0, 0);           \
     acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.y, acc1, 0, 0, 0);           \
     acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.z, acc2, 0, 0, 0);           \
@@ -38,11 +39,17 @@ __global__ __launch_bounds__(1024) void quad_loop(float* sink, unsigned long lon
     else { asm volatile("" :: "v"(XV.x), "v"(XV.y), "v"(XV.z), "v"(XV.w), "v"(W)); }
 #define SG(M, N) __builtin_amdgcn_sched_group_barrier(M, N, 0);
 #define BODY_T(W, X) SUPER(W.x, X[0]) SUPER(W.y, X[1]) SUPER(W.z, X[2]) SUPER(W.w, X[3])
+#define FENCE __builtin_amdgcn_sched_barrier(0);
 #define BODY_L(W, X, I, C)                                                       \
+    if (VARIANT & 32) {                                                          \
+    SUPER(W.x, X[0]) FENCE LD1(X[0], (I).x); FENCE SUPER(W.y, X[1]) FENCE LD1(X[1], (I).y); FENCE \
+    SUPER(W.z, X[2]) FENCE LD1(X[2], (I).z); FENCE SUPER(W.w, X[3]) FENCE LD1(X[3], (I).w);       \
+    LDI(I, (C) + 4); LDW(W, (C) + 2); FENCE                                      \
+    } else {                                                                     \
     SUPER(W.x, X[0]) LD1(X[0], (I).x); SUPER(W.y, X[1]) LD1(X[1], (I).y);        \
     SUPER(W.z, X[2]) LD1(X[2], (I).z); SUPER(W.w, X[3]) LD1(X[3], (I).w);        \
     LDW(W, (C) + 2); LDI(I, (C) + 4);                                            \
-    SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 3)
+    SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 3) }
     Wa = Wb = f32x4{1e-3f, 1e-3f, 1e-3f, 1e-3f};
     Ia = Ib = int4{256, 512, 768, 1024};
     Xa[0] = Xa[1] = Xa[2] = Xa[3] = Xb[0] = Xb[1] = Xb[2] = Xb[3] = f32x4{1, 1, 1, 1};
@@ -95,7 +102,7 @@ int main() {
     for (int thr : {256, 512, 1024}) {
         if (thr == 256) { run<0, 4>("full", 256); run<1, 4>("no MFMA", 256); run<2, 4>("no X reads", 256); run<4, 4>("no W/I reads", 256); run<6, 4>("MFMA only", 256); run<8, 4>("full + barrier/4 quads", 256); run<8, 8>("full + barrier/8 quads", 256); }
         if (thr == 512) { run<0, 4>("full", 512); run<1, 4>("no MFMA", 512); run<2, 4>("no X reads", 512); run<4, 4>("no W/I reads", 512); run<6, 4>("MFMA only", 512); run<8, 4>("full + barrier/4 quads", 512); run<8, 8>("full + barrier/8 quads", 512); }
-        if (thr == 1024) { run<0, 4>("full", 1024); run<1, 4>("no MFMA", 1024); run<2, 4>("no X reads", 1024); run<4, 4>("no W/I reads", 1024); run<6, 4>("MFMA only", 1024); run<8, 4>("full + barrier/4 quads", 1024); run<8, 8>("full + barrier/8 quads", 1024); }
+        if (thr == 1024) { run<32, 4>("full, AGPR + fenced order", 1024); run<40, 4>("full+barrier/4, AGPR + fenced", 1024); run<16, 4>("full, acc in AGPRs", 1024); run<24, 4>("full + barrier/4, acc in AGPRs", 1024); run<22, 4>("MFMA only, AGPR", 1024); run<0, 4>("full", 1024); run<1, 4>("no MFMA", 1024); run<2, 4>("no X reads", 1024); run<4, 4>("no W/I reads", 1024); run<6, 4>("MFMA only", 1024); run<8, 4>("full + barrier/4 quads", 1024); run<8, 8>("full + barrier/8 quads", 1024); }
     }
     return 0;
 }

@@ -502,8 +502,9 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
         seg = lc & 1
         stage_slot = np.where(seg == 0, lc >> 1, usplit[t_s] + (lc >> 1))
         upad = usplit + U // 2
-        qa = (np.bincount(g_s, weights=(seg == 0), minlength=n_groups).astype(np.int64) + 15) // 16
-        qb = (np.bincount(g_s, weights=(seg == 1), minlength=n_groups).astype(np.int64) + 15) // 16
+        # work per phase in super-steps (4 columns): the kernel skips a range's padding at that grain
+        qa = (np.bincount(g_s, weights=(seg == 0), minlength=n_groups).astype(np.int64) + 3) // 4
+        qb = (np.bincount(g_s, weights=(seg == 1), minlength=n_groups).astype(np.int64) + 3) // 4
         qa, qb = qa.reshape(n_tiles, -1), qb.reshape(n_tiles, -1)
     else:
         usplit, _, qa, qb = choose_segment_split(n_tiles, g_s, lc, counts)
@@ -558,8 +559,8 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
     max_tile_quads = int(np.diff(gptr[::2 * GROUPS_PER_TILE]).max()) if n_tiles else 0
     rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)
     rowmap[tile_of_row * (GROUP_ROWS * GROUPS_PER_TILE) + in_tile] = np.arange(n_rows, dtype=np.int32)
-    hq = np.diff(gptr).reshape(n_tiles, GROUPS_PER_TILE // 4, 4, 2).sum(1)     # [tile, class, phase]
-    phase_cost = hq.max(1).sum(1)
+    hq = gsup.reshape(n_tiles, GROUPS_PER_TILE // 4, 4, 2).sum(1)              # [tile, class, phase]
+    phase_cost = hq.max(1).sum(1)                                              # in super-steps
     return dict(usplit=usplit.astype(np.int32), uptr=uptr2.astype(np.int32), ucol=ucol2,
                 gptr=gptr.astype(np.int32), gsup=gsup.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
                 max_tile_quads=max_tile_quads, max_union=int(upad.max(initial=0)),

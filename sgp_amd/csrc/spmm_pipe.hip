@@ -6,15 +6,22 @@
 //   * the tile's staged source rows never pass through registers: every wave issues
 //     global_load_lds_dwordx4 (16 B per lane, 4 staged rows = 1 KiB per wave instruction) and the
 //     data lands in LDS behind the compute of the previous phase;
-//   * the tile's distinct-column list is cut in two SEGMENTS (A = the first uA rows, B = the
-//     rest), every group's stream is stored A-part first; a time step is two phases
+//   * the tile's distinct-column list is cut in two SEGMENTS (A = its even positions, B = the
+//     odd ones, so every group finds half of its columns in either), every group's stream is
+//     stored A-part first; a time step is two phases
 //         barrier, DMA B(t)   -> region B | MFMAs on region A
 //         barrier, DMA A(t+1) -> region A | MFMAs on region B, fold, store
 //     so one half of the stage is being refilled while the other is consumed and the DMA has a
-//     whole phase (~1.5 us) to land: 2 barriers per step, no ds_write pass, no staging VGPRs;
-//   * the operand reads are software-pipelined one quad ahead inside a wave (weights/indices two
-//     quads ahead), so the LDS latency sits under the wave's own MFMAs instead of being exposed
-//     every time the 4 waves of a SIMD fall into step at a barrier.
+//     whole phase (~2 us) to land: 2 barriers per step, no ds_write pass, no staging VGPRs;
+//   * the operand reads are software-pipelined TWO quads deep inside a wave (a quad's registers
+//     are reloaded as soon as its MFMAs have issued), so the LDS latency sits under the wave's
+//     own MFMAs instead of being exposed every time the 4 waves of a SIMD fall into step at a
+//     barrier, and a wave that runs alone at the tail of a phase still streams;
+//   * the padding of a range is skipped at the grain of one super-step (4 columns).
+// Measured structure of a step (tools/timeline_pipe.py, tools/abl_pipe.sh, tools/ubench/
+// quad_loop.hip; MI355X, T = 256): the quad loop alone sustains 75-80 ns per 16 MFMAs per SIMD
+// (the matrix pipe's 56 ns is not reachable next to 6 LDS returns per quad); staging alone needs
+// 60 % of the step (L2 misses); the two overlap to 4.3 us per step.
 #include "common.h"
 #include <stdlib.h>
 
@@ -39,7 +46,6 @@ struct PipeArgs {
     float* Y; long long yrs, ybs;
     int n_rows, batch, feat;
     int t_chunk, n_tchunks;
-    int map;
     unsigned* dbg;                         // timeline stamps (ablation builds only)
 };
 
@@ -71,29 +77,15 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     // XCD-aware decode (workgroup ids are dealt round-robin to the 8 XCDs -- a speed assumption
-    // only).  map 0: XCD x sweeps the tiles of "its" time chunks; map 1: every XCD owns a
-    // contiguous 1/8 of the tiles and all XCDs walk the time chunks together, so that the rows
-    // an XCD re-fetches at the edge of its tile range were recently fetched by its neighbour
-    // (Infinity Cache) instead of coming from HBM again.
+    // only): consecutive ids on one XCD = consecutive tiles of one time chunk, so the workgroups
+    // that share an L2 stage overlapping source rows of the same time steps.  (Measured without
+    // gain: every XCD owning 1/8 of the tiles with all XCDs walking the chunks together.)
+    const int nwg = a.n_tiles * a.n_tchunks;
     const int orig = blockIdx.x;
-    const int xcd = orig & 7;
-    int tile, tchunk, wg;
-    if (a.map == 0) {
-        const int nwg = a.n_tiles * a.n_tchunks;
-        const int qq = nwg >> 3, rr = nwg & 7;
-        wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-        tile = wg % a.n_tiles;
-        tchunk = wg / a.n_tiles;
-    } else {
-        const int tq = a.n_tiles >> 3, tr = a.n_tiles & 7;
-        const int t0 = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-        const int cnt = tq + (xcd < tr ? 1 : 0);
-        const int local = orig >> 3;
-        if (local >= cnt * a.n_tchunks) return;
-        tchunk = local / cnt;
-        tile = t0 + local % cnt;
-        wg = tchunk * a.n_tiles + tile;
-    }
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
+    const int tile = wg % a.n_tiles;
+    const int tchunk = wg / a.n_tiles;
     const int f_base = blockIdx.y * 64;
 
     const int tid = threadIdx.x;
@@ -341,10 +333,7 @@ int pipe_chunk_cap() {
     return v;
 }
 
-unsigned pipe_grid(const PipeArgs& a) {
-    if (a.map == 0) return (unsigned)(a.n_tiles * a.n_tchunks);
-    return 8u * (unsigned)(((a.n_tiles + 7) / 8) * a.n_tchunks);
-}
+unsigned pipe_grid(const PipeArgs& a) { return (unsigned)(a.n_tiles * a.n_tchunks); }
 
 template <bool HALO>
 int launch_pipe(const PipeArgs& a, hipStream_t s) {
@@ -434,7 +423,6 @@ int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* u
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
     a.dbg = nullptr;
-    { static int m = -1; if (m < 0) { const char* e = getenv("SGP_PIPE_MAP"); m = e ? atoi(e) : 0; } a.map = m; }
 #ifdef SGP_ABLATION
     a.dbg = pipe_dbg_buffer();
 #endif

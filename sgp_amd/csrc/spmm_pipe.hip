@@ -171,19 +171,30 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     const long long x_inc = a.src.xbs * 4, h_inc = a.src.xhbs * 4;
     const char* const x_step0 = x_step;
     const char* const h_step0 = h_step;
+    // which of the (up to 7) pieces of this wave belong to segment A / B: one bit per piece, kept
+    // in two scalars (14 separate booleans cost 28 SGPRs and push the compiler into spilling
+    // SGPRs to VGPR lanes, i.e. v_readlane -- VALU work -- inside the time loop)
+    unsigned piecesA = 0, piecesB = 0;
+#pragma unroll
+    for (int p = 0; p < kPasses; ++p) {
+        const int r0 = p * 64 + wave * 4;
+        if (r0 < uA) piecesA |= 1u << p;
+        else if (r0 < nU) piecesB |= 1u << p;
+    }
+    piecesA = __builtin_amdgcn_readfirstlane(piecesA);
+    piecesB = __builtin_amdgcn_readfirstlane(piecesB);
+    const unsigned piece0 = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)wave * 1024u);
     // (xt, ht) = base of the step whose rows are fetched
-    auto dma_segment = [&](const char* xt, const char* ht, bool seg_b) {
+    auto dma_segment = [&](const char* xt, const char* ht, unsigned pieces) {
         if constexpr (ABL & 1) return;                    // ablation: no staging traffic
         if constexpr (ABL & 4) { xt = x_step0; ht = h_step0; }   // ablation: staging hits L2
 #pragma unroll
         for (int p = 0; p < kPasses; ++p) {
-            const int r0 = p * 64 + wave * 4;             // scalar
-            const bool mine = seg_b ? (r0 >= uA && r0 < nU) : (r0 < uA);
-            if (mine) {
-                const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)r0 * 256u);
+            if (pieces & (1u << p)) {                     // scalar
+                const unsigned dst = piece0 + (unsigned)p * 16384u;
                 if constexpr (HALO) {
                     const char* b = ((halo_mask >> p) & 1u) ? ht : xt;
-                    dma16_vaddr(b + voff[p], dst);
+                    dma16_vaddr(b + voff[p], __builtin_amdgcn_readfirstlane(dst));
                 } else {
                     dma16_saddr(voff[p], xt, dst);
                 }
@@ -191,7 +202,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         }
     };
     __syncthreads();                                      // stream visible to every wave
-    dma_segment(x_step, h_step, false);
+    dma_segment(x_step, h_step, piecesA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // Operand pipeline of a wave, two quads deep.  Quad c uses register set c & 1:
@@ -274,10 +285,10 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         // anyway) and after their quads by the older half: an LDS-DMA piece costs its wave
         // 150+ cycles of issue, which must not idle the matrix pipe at the start of the phase
         const bool dma_first = wave >= 8;
-        if (dma_first) dma_segment(x_step, h_step, true);
+        if (dma_first) dma_segment(x_step, h_step, piecesB);
         stamp(t, 2);
         SGP_PHASE(wA, iA, nA, lastA)
-        if (!dma_first) dma_segment(x_step, h_step, true);
+        if (!dma_first) dma_segment(x_step, h_step, piecesB);
         // ---- phase B
         SGP_PRE(wB, iB)
         stamp(t, 3);
@@ -285,9 +296,9 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         stamp(t, 4);
         asm volatile("s_barrier" ::: "memory");
         stamp(t, 5);
-        if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, false);
+        if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         SGP_PHASE(wB, iB, nB, lastB)
-        if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, false);
+        if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         stamp(t, 6);
 
         // sum the 4 column classes; class q keeps row q (see spmm.hip)

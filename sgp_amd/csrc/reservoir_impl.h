@@ -60,7 +60,10 @@ struct ResArgs {
 // stays busy while another wave runs its activation / loads / stores)
 constexpr int min_waves(int JT, int NT) { return JT <= 4 ? 4 : (JT <= 8 ? 2 : 1); }
 
-template <int JT, int NKX, int NT, bool WLDS>
+// XVEC / OVEC: 16-byte input loads / state stores (strides and pointers checked on the host).  A compile
+// time switch, not a branch inside the time loop: with both paths in one loop body the compiler's
+// s_waitcnt bookkeeping merges their pending loads and serialises every step on vmcnt(0).
+template <int JT, int NKX, int NT, bool WLDS, bool XVEC, bool OVEC>
 __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float* wsrc = a.wp;
@@ -102,11 +105,15 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
             }
         }
     }
-    const bool x_vec = (NKX % 4 == 0) && (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.x) & 15u) == 0);
-    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+    constexpr bool x_vec = XVEC && (NKX % 4 == 0);
+    constexpr bool o_vec = OVEC;
 
+    // Retire the initial-state loads HERE, with a wait the compiler can see: otherwise it carries
+    // "h may still be in flight" into the loop and, because loads and stores are both pending
+    // there, guards the first MFMA of every step with s_waitcnt vmcnt(0) -- which waits for the
+    // input rows that were requested a moment ago instead of letting them land under the
+    // recurrent part.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
     for (int t = 0; t < a.T; ++t) {
         // Keep the weight fragments in LDS/L2: without this the compiler hoists all of them
         // out of the time loop into ~128 VGPRs and occupancy drops to one wave per SIMD.
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
             float xr[NKX];
             {
                 const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
-                if (x_vec) {
+                if constexpr (x_vec) {
 #pragma unroll
                     for (int k4 = 0; k4 < NKX / 4; ++k4) {
                         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
                 const int j0 = 16 * jt + 4 * q;
                 if (ok[i] && j0 < a.R) {
                     float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
-                    if (o_vec) {
+                    if constexpr (o_vec) {
                         *reinterpret_cast<f32x4*>(op) = h[i][jt];
                     } else {
 #pragma unroll
@@ -388,14 +395,20 @@ int launch_layer(ResArgs a, hipStream_t s) {
         wpw = 4;
         grid = n_waves / wpw;
     }
-    if constexpr (packed_floats(JT, NKX) * 4 <= kLdsLimit) {
-        auto kern = reservoir_layer<JT, NKX, NT, true>;
+    const bool xv = (NKX % 4 == 0) && (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x);
+    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+    void (*kern)(ResArgs);
+    constexpr bool kLds = packed_floats(JT, NKX) * 4 <= kLdsLimit;
+    if (xv && ov) kern = reservoir_layer<JT, NKX, NT, kLds, true, true>;
+    else if (ov) kern = reservoir_layer<JT, NKX, NT, kLds, false, true>;
+    else kern = reservoir_layer<JT, NKX, NT, kLds, false, false>;
+    if constexpr (kLds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)wbytes);
         if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
         hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)wbytes, s, a);
     } else {
-        hipLaunchKernelGGL((reservoir_layer<JT, NKX, NT, false>), dim3(grid), dim3(64 * wpw), 0, s, a);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), 0, s, a);
     }
     return sgp::check_launch("reservoir_layer");
 }

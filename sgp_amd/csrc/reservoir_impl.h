@@ -262,17 +262,52 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
     f32x4 h[JT];                                         // full state as B operands
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) {
-        h[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};
         if (a.h_state && ok) {
             const int j0 = 16 * jt + 4 * q;
+            const float* hp = a.h_state + (long long)node * a.R + j0;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (j0 + r < a.R) h[jt][r] = a.h_state[(long long)node * a.R + j0 + r];
+                if (j0 + r < a.R) hv[r] = hp[r];
         }
+        h[jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
     }
     const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
                        ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
     __syncthreads();
+
+    // The step is a serial chain (MFMAs -> activation -> LDS exchange -> barrier), so nothing
+    // may wait for memory inside it: the input row of step t+1 is requested at the top of step
+    // t, and the state of step t-1 is stored at the top of step t -- both have a whole step to
+    // complete before the next s_waitcnt vmcnt(0) (loads and stores share that counter).
+    auto load_x = [&](int t, float (&dst)[NKX]) {
+        const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks)
+            dst[ks] = (ok && q * NKX + ks < a.F) ? xp[ks] : 0.f;
+    };
+    auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            const int j0 = 16 * (wave * JW + w) + 4 * q;
+            if (ok && j0 < a.R) {
+                float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
+                if (o_vec) {
+                    *reinterpret_cast<f32x4*>(op) = hv[w];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + r < a.R) op[r] = hv[w][r];
+                }
+            }
+        }
+    };
+    float xr[NKX];
+    f32x4 hprev[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) hprev[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.T > 0) load_x(0, xr);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), visible to the compiler
 
     for (int t = 0; t < a.T; ++t) {
         int wo = 0;
@@ -280,13 +315,11 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
         const float* bias_t = bias + wo;
         const float* wx_t = wx + wo;
         const float* wh_t = wh + wo;
-        float xr[NKX];
-        {
-            const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+        if (t > 0) store_h(t - 1, hprev);
+        float xn[NKX];
 #pragma unroll
-            for (int ks = 0; ks < NKX; ++ks)
-                xr[ks] = (ok && q * NKX + ks < a.F) ? xp[ks] : 0.f;
-        }
+        for (int ks = 0; ks < NKX; ++ks) xn[ks] = 0.f;
+        if (t + 1 < a.T) load_x(t + 1, xn);
         f32x4 acc[JW];
 #pragma unroll
         for (int w = 0; w < JW; ++w)
@@ -340,7 +373,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[w][r] *= inv;
         }
-        // leak, publish my tiles, store them
+        // leak, publish my tiles (they are stored to HBM at the top of the next step)
 #pragma unroll
         for (int w = 0; w < JW; ++w) {
             const int jt = wave * JW + w;
@@ -349,22 +382,15 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             for (int r = 0; r < 4; ++r)
                 hn[r] = a.one_minus_alpha * h[jt][r] + a.alpha * acc[w][r];
             hb[jt * 64 + lane] = hn;
-            const int j0 = 16 * jt + 4 * q;
-            if (ok && j0 < a.R) {
-                float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
-                if (o_vec) {
-                    *reinterpret_cast<f32x4*>(op) = hn;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (j0 + r < a.R) op[r] = hn[r];
-                }
-            }
+            hprev[w] = hn;
         }
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) xr[ks] = xn[ks];
         __syncthreads();
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) h[jt] = hb[jt * 64 + lane];
     }
+    if (a.T > 0) store_h(a.T - 1, hprev);
     if (a.h_state && wave == 0) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {

@@ -260,6 +260,21 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     };
     issue(t_begin);
 
+    // The result rows of step t are kept in registers and stored at the top of step t+1, after the
+    // wait that retires the staged loads: loads and stores share vmcnt, and a store issued at the
+    // end of step t would make that wait sit out a full store round trip every step.
+    f32x4 res[RPG];
+#pragma unroll
+    for (int g = 0; g < RPG; ++g) res[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto store_rows = [&](int t) {
+#pragma unroll
+        for (int g = 0; g < RPG; ++g) {
+            const int rr = eg + g * NEG;
+            if (rr < rows_here)
+                st4(a.Y + (long long)t * a.ybs + (long long)(row0 + rr) * a.yrs + f_base + li * 4, res[g]);
+        }
+    };
+
     for (int t = t_begin; t < t_end; ++t) {
         if constexpr (kStage) {
 #pragma unroll
@@ -267,12 +282,12 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
                 if (p < n_pass)
                     *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
         }
+        if (t > t_begin) store_rows(t - 1);
         if constexpr (kBarrier) __syncthreads();
         if (t + 1 < t_end) issue(t + 1);          // in flight under the compute below
 
 #pragma unroll
         for (int g = 0; g < RPG; ++g) {
-            const int rr = eg + g * NEG;
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
@@ -287,11 +302,11 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
                     }
                 }
             }
-            if (rr < rows_here)
-                st4(a.Y + (long long)t * a.ybs + (long long)(row0 + rr) * a.yrs + f_base + li * 4, acc);
+            res[g] = acc;
         }
         if constexpr (kBarrier) __syncthreads();   // all reads done before the next overwrite
     }
+    store_rows(t_end - 1);
 }
 
 int tiled_variant();

@@ -464,6 +464,9 @@ def place_groups_two_phase(qa, qb):
             la[best] += a
             lb[best] += b
             used[best] += 1
+    # (groups were dealt longest first, so inside a class the heaviest group sits in the lowest
+    # wave slot: the SIMD serves its oldest wave first, the youngest -- which only gets the
+    # matrix pipe's leftovers and finishes last -- carries the least work)
     return new_slot
 
 

@@ -149,3 +149,24 @@ def test_properties():
     y = torch.cat(O.spatial_embedding(x, ei, ew, k=2), -1)
     yp = torch.cat(O.spatial_embedding(x[:, perm], inv[ei], ew, k=2), -1)
     close(yp, y[:, perm])
+
+
+# ------------------------------------------------------------------ f1: IID sampling
+@pytest.mark.parametrize("name", golden_files("g7_iid_"))
+def test_iid_sampling(name):
+    """oracle restatement of IIDDataset.sample == what the reference returned (indices, inputs,
+    targets; RNG order; scaler applied after the gather)."""
+    z = load(name)
+    hz, delay, lag, n = [int(v) for v in z["cfg"]]
+    emb, y, u = (torch.from_numpy(z[k]) for k in ("emb", "y", "u"))
+    torch.manual_seed(int(z["seed"]))
+    st, nd = O.iid_draw(emb.shape[0], emb.shape[1], hz, n)
+    assert np.array_equal(st.numpy(), z["step_index"])
+    assert np.array_equal(nd.numpy(), z["node_index"])
+    assert np.array_equal(O.iid_gather_input(emb, "t n f", st, nd).numpy(), z["out_x"])
+    ty = O.iid_gather_target(y, "t n f", O.iid_horizon_index(st, delay, hz, lag), nd)
+    if bool(z["has_scaler"]):
+        ty = (ty - torch.from_numpy(z["bias"])) / torch.from_numpy(z["scale"])
+    assert np.array_equal(ty.numpy(), z["out_y"])
+    if bool(z["has_exo"]):
+        assert np.array_equal(O.iid_gather_input(u, "t f", st, nd).numpy(), z["out_u"])

@@ -20,6 +20,8 @@
  *       output slot; the fused path writes slots in place and never concatenates.
  *   sgp_gather_rows_f32
  *       lib/datasets/iid_dataset.py:57-99 (IID (t, n) row gather of the embedding; "next" row f1)
+ *   sgp_grouped_linear_f32
+ *       lib/nn/models/sgp_model.py:41-52 (decoder input encoder: grouped Conv1d + activation; f4)
  *
  * Conventions
  *   - All pointers are DEVICE pointers owned by the caller (e.g. the PyTorch
@@ -248,6 +250,25 @@ int sgp_gather_rows_f32(const float* X, int64_t x_row_stride, int64_t x_batch_st
                         const int32_t* step, const int32_t* node, int32_t n_index,
                         float* out, int64_t out_row_stride, int64_t out_batch_stride,
                         int32_t batch, int32_t feat, sgp_stream_t stream);
+
+/* ------------------------------------------------- Decoder first layer ("next" row f4) ---
+ * Grouped 1x1 convolution of lib/nn/models/sgp_model.py:41-52 (nn.Conv1d(input_size, out_channels,
+ * kernel_size=1, groups) between two Rearranges, then the activation): for every row
+ *   out[row, g*oc + o] = act(bias[g*oc + o] + sum_i W[g*oc + o, i] * X_row[g*ic + i]),  g < groups.
+ * Row k is X[k, :] (x_row_stride) or, when step / node are given, X[step[k], node[k], :] -- the IID
+ * gather of lib/datasets/iid_dataset.py:66-69 fused in, so the sampled batch never exists in HBM.
+ * W is Conv1d's weight [groups*oc, ic] (trailing kernel axis of size 1 dropped), handed over in the
+ * fragment order produced by sgp_grouped_linear_pack_f32 (sgp_grouped_linear_packed_floats floats).
+ * act: 0 = none, 1 = relu, 2 = silu.  fp32 MFMA (v_mfma_f32_16x16x4_f32), exact products. */
+int64_t sgp_grouped_linear_packed_floats(int32_t groups, int32_t ic, int32_t oc);
+int sgp_grouped_linear_pack_f32(const float* w, float* packed, int32_t groups, int32_t ic, int32_t oc,
+                                sgp_stream_t stream);
+int sgp_grouped_linear_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                           const int32_t* step, const int32_t* node,
+                           const float* w_packed, const float* bias, int32_t act,
+                           float* out, int64_t out_row_stride,
+                           int32_t n_rows, int32_t groups, int32_t ic, int32_t oc,
+                           sgp_stream_t stream);
 
 /* -------------------------------------------------------------- Timing -----
  * HIP-event helpers so that Python can time kernels on the stream they were

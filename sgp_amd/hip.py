@@ -77,6 +77,10 @@ SIGNATURES = {
                                          c_i32, c_i32, c_i32, c_p]),
     "sgp_gather_rows_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i32,
                                            c_p, c_i64, c_i64, c_i32, c_i32, c_p]),
+    "sgp_grouped_linear_packed_floats": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgp_grouped_linear_pack_f32": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
+    "sgp_grouped_linear_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
+                                              c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_event_create": (ctypes.c_int, [ctypes.POINTER(c_p)]),
     "sgp_event_destroy": (ctypes.c_int, [c_p]),
     "sgp_event_record": (ctypes.c_int, [c_p, c_p]),
@@ -416,6 +420,42 @@ def gather_rows(x, step_index, node_index):
     out = torch.empty(K, D, dtype=torch.float32, device=x.device)
     _check(lib.sgp_gather_rows_f32(xp, xrs, xbs, step_index.data_ptr(), node_index.data_ptr(), K,
                                    out.data_ptr(), D, 0, 1, D, _stream(x)), "sgp_gather_rows_f32")
+    return out
+
+
+GL_ACT_CODES = {None: 0, "linear": 0, "identity": 0, "relu": 1, "silu": 2}
+
+
+def grouped_linear_pack(weight, groups):
+    """Conv1d weight [groups*oc, ic(, 1)] (CUDA) -> MFMA fragment order."""
+    lib = require_gpu()
+    w = weight.reshape(weight.shape[0], -1).contiguous().float()
+    oc, ic = w.shape[0] // groups, w.shape[1]
+    packed = torch.empty(lib.sgp_grouped_linear_packed_floats(groups, ic, oc), dtype=torch.float32,
+                         device=w.device)
+    _check(lib.sgp_grouped_linear_pack_f32(w.data_ptr(), packed.data_ptr(), groups, ic, oc, _stream(w)),
+           "sgp_grouped_linear_pack_f32")
+    return packed
+
+
+def grouped_linear(x2, packed, bias, groups, ic, oc, activation, step_index=None, node_index=None,
+                   source=None):
+    """rows [K, groups*ic] -> [K, groups*oc]; with (step_index, node_index) the rows are gathered
+    from ``source[T, N, groups*ic]`` instead of being read from ``x2``."""
+    lib = require_gpu()
+    if source is not None:
+        xp, xrs, xbs = _view3(source, "source")
+        K = node_index.numel()
+        sp, np_ = step_index.data_ptr(), node_index.data_ptr()
+        dev = source.device
+    else:
+        if x2.dim() != 2 or x2.stride(1) != 1:
+            raise ValueError("grouped_linear: rows must be a 2-D view with unit feature stride")
+        xp, xrs, xbs, K, sp, np_, dev = x2.data_ptr(), x2.stride(0), 0, x2.shape[0], None, None, x2.device
+    out = torch.empty(K, groups * oc, dtype=torch.float32, device=dev)
+    _check(lib.sgp_grouped_linear_f32(xp, xrs, xbs, sp, np_, packed.data_ptr(), bias.data_ptr(),
+                                      GL_ACT_CODES[activation], out.data_ptr(), out.stride(0),
+                                      K, groups, ic, oc, _stream(out)), "sgp_grouped_linear_f32")
     return out
 
 

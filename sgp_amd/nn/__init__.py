@@ -1,1 +1,1 @@
-from . import encoders, reservoir
+from . import encoders, models, reservoir

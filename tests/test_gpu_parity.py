@@ -474,6 +474,38 @@ def test_iid_sampler_on_encoder_output():
     assert torch.equal(out["target"]["y"].cpu(), O.iid_gather_target(x[:, :, :1], "t n f", hor, ni))
 
 
+@pytest.mark.parametrize("name", golden_files("g8_decoder_"))
+def test_decoder_input_encoder_matches_reference(name):
+    """sgp_amd.nn.models.SGPInputEncoder (grouped 1x1 conv + activation on the fp32 matrix cores)
+    == the reference SGPModel's input_encoder on the recorded parameters; also fused with the IID
+    gather."""
+    from sgp_amd.nn.models import SGPInputEncoder
+    z = load(name)
+    f, order, hidden = [int(v) for v in z["cfg"]]
+    act = str(z["activation"])
+    torch.manual_seed(int(z["seed"]))
+    enc = SGPInputEncoder(f, order, hidden, activation=act)
+    assert tuple(enc.weight.shape) == z["weight"].shape            # reference parameter shapes
+    enc.weight.data.copy_(torch.from_numpy(z["weight"])); enc.bias.data.copy_(torch.from_numpy(z["bias"]))
+    x = torch.from_numpy(z["x"])
+    y = enc(x.cuda())
+    close(y, z["y"])
+    r64 = torch.from_numpy(z["y64"])
+    assert float(((y.cpu().double() - r64).abs() / r64.abs().clamp_min(1)).max()) < 5e-6
+    # strided rows (a slot range of a wider buffer) and the host-tensor convenience path
+    xin = x[:, -1] if x.dim() == 4 else x
+    wide = torch.randn(xin.shape[0], xin.shape[1], f + 8).cuda()
+    wide[:, :, 4:4 + f] = xin.cuda()
+    close(enc(wide[:, :, 4:4 + f]), z["y"])
+    close(enc(x), z["y"])
+    # fused with the IID gather: rows (b, n) of xin in a shuffled order
+    emb = xin.cuda().contiguous()
+    k = 3 * xin.shape[0] * xin.shape[1]
+    si = torch.randint(0, xin.shape[0], (k,)); ni = torch.randint(0, xin.shape[1], (k,))
+    ys = enc.forward_sampled(emb, si, ni)
+    close(ys[:, 0], torch.from_numpy(z["y"])[si, ni])
+
+
 def test_properties_at_scale():
     """Size-independent checks on a graph too large for the dense oracle."""
     torch.manual_seed(8)

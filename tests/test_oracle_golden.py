@@ -170,3 +170,15 @@ def test_iid_sampling(name):
     assert np.array_equal(ty.numpy(), z["out_y"])
     if bool(z["has_exo"]):
         assert np.array_equal(O.iid_gather_input(u, "t f", st, nd).numpy(), z["out_u"])
+
+
+# ------------------------------------------------------------------ f4: decoder input layer
+@pytest.mark.parametrize("name", golden_files("g8_decoder_"))
+def test_decoder_input_encoder(name):
+    z = load(name)
+    f, order, hidden = [int(v) for v in z["cfg"]]
+    x, w, b = (torch.from_numpy(z[k]) for k in ("x", "weight", "bias"))
+    y = O.decoder_input_encoder(x, w, b, order, str(z["activation"]))
+    close(y, z["y"])
+    y64 = O.decoder_input_encoder(x.double(), w.double(), b.double(), order, str(z["activation"]))
+    close(y64, z["y64"], rtol=1e-10, atol=1e-10)

@@ -170,6 +170,25 @@ class SparseTensor:
     def to_dense(self):
         return self.to_dense_matrix()
 
+    def index_select(self, dim, idx):
+        """torch_sparse ``SparseTensor.index_select``: keep the listed rows (dim 0) / columns
+        (dim 1) in the order given, repeats allowed."""
+        idx = torch.as_tensor(idx, dtype=torch.long)
+        m, n = self._sizes
+        a, b = (self._row, self._col) if dim == 0 else (self._col, self._row)
+        size = m if dim == 0 else n
+        order = torch.argsort(a, stable=True)
+        counts = torch.bincount(a, minlength=size)
+        start = torch.cumsum(counts, 0) - counts
+        take = torch.cat([order[start[i]:start[i] + counts[i]] for i in idx.tolist()]) \
+            if idx.numel() else torch.zeros(0, dtype=torch.long)
+        new_a = torch.repeat_interleave(torch.arange(idx.numel()), counts[idx])
+        new_b = b[take]
+        val = None if self._value is None else self._value[take]
+        if dim == 0:
+            return SparseTensor(row=new_a, col=new_b, value=val, sparse_sizes=(idx.numel(), n))
+        return SparseTensor(row=new_b, col=new_a, value=val, sparse_sizes=(m, idx.numel()))
+
     def __matmul__(self, other):
         return matmul(self, other)
 

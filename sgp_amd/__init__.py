@@ -2,7 +2,7 @@
 (reservoir over time + K-hop graph-shift propagation over nodes) behind the reference's own
 Python surface.  Compute lives in ``csrc/libsgp_amd.so`` (hand-written HIP for gfx950); there
 is no CPU fallback."""
-from . import datasets, hip
+from . import dataloader, datasets, hip
 from .graph import ShiftOperator
 from .nn.encoders import GESNEncoder, SGPEncoder, SGPSpatialEncoder, SGPTemporalEncoder
 from .nn.reservoir import GESNLayer, GraphESN, Reservoir, ReservoirLayer

@@ -1,0 +1,53 @@
+"""On-the-fly spatial supports on the GPU -- the compute of "next" row f3.
+
+With ``sgp_preprocessing: True`` the reference does not precompute the embedding: its loaders
+apply the explicit supports of ``sgp_spatial_support`` to every sample,
+
+* ``SGPLoader.collate`` (``lib/dataloader/sgp_dataloader.py:57-61``):
+  ``sample[key] = torch.cat([x] + [adj @ x for adj in support], dim=-1)``
+* ``IIDDataset._populate_input_frame`` (``lib/datasets/iid_dataset.py:111-114``) for a node subset:
+  ``torch.cat([tens.index_select(1, node_index)] +
+  [adj.index_select(0, node_index) @ tens for adj in self.sgp_support], dim=-1)``
+
+``apply_supports`` is that expression with the products on the MI355X (``sgp_spmm_csr_f32`` on
+the supports' CSR, rectangular for a node subset) and every block written straight into its slot
+of the result (no ``torch.cat``).  The supports come from ``sgp_amd.sgp_spatial_support`` (the
+reference's quirks included); a dense support (``global_attr``'s 1/N matrix) is a plain matmul.
+The DataLoader / Batch plumbing around these lines is tsl's and is not rebuilt here.
+"""
+import torch
+
+from .. import hip
+from ..graph import ShiftOperator
+
+
+def apply_supports(x, support, node_index=None):
+    """x[..., N, F] -> [..., N (or len(node_index)), (1 + len(support)) * F]."""
+    hip.require_gpu()
+    dev_in = x.device
+    xg = x.float()
+    if not xg.is_cuda:
+        xg = xg.cuda()
+    lead = xg.shape[:-2]
+    n, f = xg.shape[-2:]
+    x3 = xg.reshape(-1, n, f)
+    if x3.stride(2) != 1:
+        x3 = x3.contiguous()
+    idx = None if node_index is None else torch.as_tensor(node_index, dtype=torch.long)
+    rows = n if idx is None else idx.numel()
+    out = torch.empty(x3.shape[0], rows, (1 + len(support)) * f, dtype=torch.float32, device=xg.device)
+    if idx is None:
+        hip.copy_rows(x3, out[:, :, :f])
+    else:
+        hip.gather_nodes(x3, idx.to(xg.device, torch.int32), out[:, :, :f])
+    for s, adj in enumerate(support, start=1):
+        dst = out[:, :, s * f:(s + 1) * f]
+        if isinstance(adj, ShiftOperator):
+            op = adj if idx is None else adj.index_select(0, idx)
+            op.propagate_rect(x3, dst)
+        else:                                        # dense support (global_attr: 1/N everywhere)
+            a = torch.as_tensor(adj, dtype=torch.float32).to(xg.device)
+            a = a if idx is None else a[idx.to(xg.device)]
+            dst.copy_(torch.matmul(a, x3))
+    out = out.reshape(*lead, rows, out.shape[-1])
+    return out if dev_in == out.device else out.to(dev_in)

@@ -193,6 +193,31 @@ class ShiftOperator:
             hip.spmm_csr(rowptr, col, val, x, y, halo, self.num_nodes)
         return y
 
+    def index_select(self, dim, index):
+        """Rows ``index`` (order kept, repeats allowed) as a new rectangular operator -- the
+        ``adj.index_select(0, node_index)`` of lib/datasets/iid_dataset.py:113."""
+        if dim != 0:
+            raise NotImplementedError("only row selection (dim=0) is used by the reference")
+        idx = torch.as_tensor(index, dtype=torch.long).cpu()
+        rp = self.rowptr.long()
+        counts = (rp[1:] - rp[:-1])[idx]
+        new_rp = torch.zeros(idx.numel() + 1, dtype=torch.long)
+        new_rp[1:] = torch.cumsum(counts, 0)
+        take = torch.repeat_interleave(rp[idx] - new_rp[:-1], counts) + torch.arange(int(new_rp[-1]))
+        return ShiftOperator(new_rp, self.col[take], self.val[take], idx.numel(), num_cols=self.num_cols)
+
+    def propagate_rect(self, x, y):
+        """y[b] = A x[b] for an operator whose columns all address ``x`` (square, or the rectangular
+        row subset made by ``index_select``): generic CSR kernel, no halo."""
+        from . import hip
+        if x.shape[1] != self.num_cols or y.shape[1] != self.num_nodes:
+            raise ValueError("operand shapes do not match the operator")
+        if self.num_cols == self.num_nodes:
+            return self.propagate(x, y)
+        rowptr, col, val = self.device_csr(x.device)
+        hip.spmm_csr(rowptr, col, val, x, y)
+        return y
+
     def __matmul__(self, x):
         if not torch.is_tensor(x) or x.dim() < 2:
             raise TypeError("ShiftOperator @ expects a dense tensor [..., N, F]")

@@ -506,6 +506,26 @@ def test_decoder_input_encoder_matches_reference(name):
     close(ys[:, 0], torch.from_numpy(z["y"])[si, ni])
 
 
+@pytest.mark.parametrize("name", golden_files("g9_onthefly_"))
+def test_onthefly_supports_match_reference(name):
+    """sgp_amd.dataloader.apply_supports (supports applied on the GPU, blocks written in place)
+    == the reference's collate / node-subset expressions on the reference's own supports."""
+    from sgp_amd.dataloader import apply_supports
+    z = load(name)
+    kw = {k: (bool(z[k]) if z[k].dtype == bool else int(z[k])) for k in
+          ("k", "undirected", "add_self_loops", "remove_self_loops", "bidirectional", "global_attr")
+          if k in z.files}
+    ei, ew, n = torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_weight"]), int(z["n"])
+    sup = sgp_amd.sgp_spatial_support(ei, ew, num_nodes=n, **kw)
+    x = torch.from_numpy(z["x"])
+    full = apply_supports(x.cuda(), sup)
+    assert full.is_cuda
+    close(full, z["full"])
+    close(apply_supports(x, sup), z["full"])                       # host tensor in, host tensor out
+    close(apply_supports(x.cuda(), sup, torch.from_numpy(z["node_index"])), z["sub"])
+    close(apply_supports(x[0].cuda(), sup), z["full"][0])          # a single [N, F] frame
+
+
 def test_properties_at_scale():
     """Size-independent checks on a graph too large for the dense oracle."""
     torch.manual_seed(8)

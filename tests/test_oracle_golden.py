@@ -182,3 +182,17 @@ def test_decoder_input_encoder(name):
     close(y, z["y"])
     y64 = O.decoder_input_encoder(x.double(), w.double(), b.double(), order, str(z["activation"]))
     close(y64, z["y64"], rtol=1e-10, atol=1e-10)
+
+
+# ------------------------------------------------------------------ f3: on-the-fly supports
+@pytest.mark.parametrize("name", golden_files("g9_onthefly_"))
+def test_onthefly_supports(name):
+    z = load(name)
+    kw = {k: (bool(z[k]) if z[k].dtype == bool else int(z[k])) for k in
+          ("k", "undirected", "add_self_loops", "remove_self_loops", "bidirectional", "global_attr")
+          if k in z.files}
+    ei, ew, n = torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_weight"]), int(z["n"])
+    sup = O.spatial_support_dense(ei, ew, n, **kw)
+    x = torch.from_numpy(z["x"])
+    close(O.apply_supports_dense(x, sup), z["full"])
+    close(O.apply_supports_dense(x, sup, torch.from_numpy(z["node_index"])), z["sub"])

@@ -6,7 +6,7 @@ Default workload = the target line of BASELINE.json's north_star / BASELINE.md 3
 N = 100 000 nodes, 100-NN geometric graph (Morton order), T = 1024, F_in = 64, reservoir 64 x 1,
 K = 4  ->  D_out = 320, 131 GB of output, 157 GB resident.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c3|c2|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c1|c2|c3|c4|c5|small]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the SAME graph is node-partitioned across the ranks (strong scaling): reservoir
@@ -38,6 +38,11 @@ WORKLOADS = {
     "c3": dict(N=10000, T=2016, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
     "c2": dict(N=325, T=52116, F=3, R=128, L=1, K=4, bidir=True, glob=True, graph="traffic"),
     "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=True, glob=True, graph="knn100"),
+    # BASELINE.json configs[4]: 629 GB of embedding -> produced in time chunks of t_chunk steps
+    # through a ring buffer (the recurrence is carried in a device-resident state, the chunk is
+    # overwritten by the next one: benchmark mode "encode and discard")
+    "c5": dict(N=100000, T=1024, F=128, R=256, L=1, K=5, bidir=False, glob=False, graph="knn100",
+               t_chunk=256),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # Fabric-side bytes of one hop launch from rocprofv3 PMC passes of this very command
@@ -140,7 +145,11 @@ def main():
     else:
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         x = torch.randn(T, n_own, F, device=dev, generator=g)   # synthetic, resident in HBM
-    out = torch.empty(T, n_own, enc.output_size, device=dev)
+    # time chunk per pass of the hot path (the whole sequence unless the embedding exceeds HBM;
+    # node-partitioned ranks hold 1/world of it)
+    tc = min(T, max(1, w.get("t_chunk", T) * world))
+    out = torch.empty(tc, n_own, enc.output_size, device=dev)
+    state = torch.zeros(L, n_own, R, device=dev) if tc < T else None
     for o in local_ops:                                     # plans + device CSR built once
         o.tile_plan(d_h, dev)
         o.device_csr(dev)
@@ -148,27 +157,31 @@ def main():
     hop_ms = []
 
     def step(timed):
-        enc.reservoir.encode_into(x, out[:, :, :d_h])
-        if world == 1:
-            # hops launched one by one so each can be bracketed by HIP events on its stream
-            for d, op in enumerate(ops):
-                src = out[:, :, :d_h]
-                for h in range(K):
-                    s = 1 + d * K + h
-                    dst = out[:, :, s * d_h:(s + 1) * d_h]
-                    if timed:
-                        a, b = hip.Event(), hip.Event()
-                        a.record()
-                    op.propagate(src, dst)
-                    if timed:
-                        b.record()
-                        hop_ms.append((a, b))
-                    src = dst
-            if w["glob"]:
-                p = enc.sgp_encoder.num_blocks() - 1
-                hip.node_mean_bcast(out[:, :, :d_h], out[:, :, p * d_h:(p + 1) * d_h])
-        else:
-            spatial.encode_into(out, d_h)
+        if state is not None:
+            state.zero_()
+        for t0 in range(0, T, tc):
+            xs, oc = x[t0:t0 + tc], out[:min(tc, T - t0)]
+            enc.reservoir.encode_into(xs, oc[:, :, :d_h], state)
+            if world == 1:
+                # hops launched one by one so each can be bracketed by HIP events on its stream
+                for d, op in enumerate(ops):
+                    src = oc[:, :, :d_h]
+                    for h in range(K):
+                        s = 1 + d * K + h
+                        dst = oc[:, :, s * d_h:(s + 1) * d_h]
+                        if timed:
+                            a, b = hip.Event(), hip.Event()
+                            a.record()
+                        op.propagate(src, dst)
+                        if timed:
+                            b.record()
+                            hop_ms.append((a, b))
+                        src = dst
+                if w["glob"]:
+                    p = enc.sgp_encoder.num_blocks() - 1
+                    hip.node_mean_bcast(oc[:, :, :d_h], oc[:, :, p * d_h:(p + 1) * d_h])
+            else:
+                spatial.encode_into(oc, d_h)
 
     def barrier():
         if world > 1:
@@ -204,12 +217,12 @@ def main():
                                    f"{'100-NN geometric graph (Morton order)' if w['graph'] == 'knn100' else 'traffic-like sparse graph'}"
                                    f"{', bidirectional' if w['bidir'] else ''}"
                                    f"{', global_attr' if w['glob'] else ''}",
-                       "nnz": nnz, "d_out": enc.output_size,
+                       "nnz": nnz, "d_out": enc.output_size, "t_chunk": tc,
                        "partition": f"{world} contiguous node block(s)"},
         }
         if hop_ms:
             per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
-            bts = hop_bytes(N, T, d_h, nnz)
+            bts = hop_bytes(N, tc, d_h, nnz)              # one launch covers one time chunk
             achieved = bts / (per_launch * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

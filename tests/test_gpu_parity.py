@@ -548,6 +548,37 @@ def test_properties_at_scale():
     assert torch.equal(ya, x1)
 
 
+def test_properties_on_the_target_graph():
+    """BASELINE's full-size graph (N = 100 000, 100-NN, the plan the bench runs on: 1700+ tiles,
+    some halved, tile streams close to the LDS limit), few time steps: every row of the
+    normalised operator sums to 1, the product is linear, and the pipelined matrix-core kernel
+    agrees with the generic CSR kernel -- checks that need no dense oracle."""
+    torch.manual_seed(9)
+    n, d, t = 100000, 64, 3
+    ei, ew, _ = synthetic.knn_graph(n, 100, seed=1)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    plan = op.tile_plan(d, torch.device("cuda"))
+    assert plan is not None and plan.pipe is not None
+    assert plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
+    x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
+    ya, yb, yc, yr = (torch.empty_like(x1) for _ in range(4))
+    op.propagate(x1, ya); assert op.last_kernel == "spmm_pipe"
+    op.propagate(x2, yb)
+    op.propagate(2 * x1 - 3 * x2, yc)
+    close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)
+    op.propagate(x1, yr, force="csr")
+    close(ya, yr, rtol=1e-5, atol=1e-5, fro=2e-6)
+    ones = torch.ones(t, n, d, device="cuda")
+    op.propagate(ones, ya)
+    close(ya, ones, atol=1e-5)
+    # a wider slot (C5: D_h = 256 = 4 feature slices) through strided views of one buffer
+    buf = torch.randn(t, n, 2 * 256, device="cuda")
+    op.propagate(buf[:, :, :256], buf[:, :, 256:])
+    ref = torch.empty(t, n, 256, device="cuda")
+    op.propagate(buf[:, :, :256].contiguous(), ref, force="csr")
+    close(buf[:, :, 256:], ref, rtol=1e-5, atol=1e-5, fro=2e-6)
+
+
 # ------------------------------------------------------------------ node partition (halo kernels)
 @pytest.mark.parametrize("world", [2, 3])
 def test_partitioned_blocks_with_halo_on_one_gpu(world):

@@ -102,6 +102,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: everything else that ends up on file descriptor 1
+    # (RCCL prints a version banner there from C, flushed at exit) is sent to stderr
+    json_fd = os.dup(1)
+    sys.stdout.flush()
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -115,7 +121,12 @@ def main():
     local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SGP_BENCH_FORCE_DIST=1: take the partitioned path (process group, halo exchange calls,
+    # all_reduce) even with one rank -- self-test of the RCCL plumbing on a single-GPU box
+    force_dist = os.environ.get("SGP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend, rank=rank, world_size=world)
 
     w = WORKLOADS[args.workload]
@@ -130,8 +141,8 @@ def main():
                              input_scaling=1., receptive_field=K, bidirectional=w["bidir"],
                              alpha_decay=L > 1, global_attr=w["glob"])
     d_h = enc.reservoir.output_size
-    if world > 1:
-        spatial, bounds = partition.make_partitioned_spatial(ops, K, w["glob"])
+    if world > 1 or force_dist:
+        spatial, bounds = partition.make_partitioned_spatial(ops, K, w["glob"], force_collectives=force_dist)
         lo, hi = bounds[rank], bounds[rank + 1]
         local_ops = [b.op for b in spatial.blocks]
     else:
@@ -162,7 +173,7 @@ def main():
         for t0 in range(0, T, tc):
             xs, oc = x[t0:t0 + tc], out[:min(tc, T - t0)]
             enc.reservoir.encode_into(xs, oc[:, :, :d_h], state)
-            if world == 1:
+            if spatial is None:
                 # hops launched one by one so each can be bracketed by HIP events on its stream
                 for d, op in enumerate(ops):
                     src = oc[:, :, :d_h]
@@ -184,7 +195,7 @@ def main():
                 spatial.encode_into(oc, d_h)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +207,7 @@ def main():
         step(True)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         tt = torch.tensor([elapsed], dtype=torch.float64,
                           device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -231,8 +242,8 @@ def main():
                                "ms_per_launch": per_launch, "algorithmic_bytes": bts}
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(w)
-        print(json.dumps(rec), flush=True)
-    if world > 1:
+        os.write(json_fd, (json.dumps(rec) + "\n").encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

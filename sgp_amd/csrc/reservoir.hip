@@ -26,9 +26,18 @@ __global__ void pack_weights(const float* __restrict__ w_ih, const float* __rest
             v = j < R ? b[j] : 0.f;
         } else if (i < n_bias + n_wx) {
             const long long o = i - n_bias;
-            const int l = (int)(o & 63);
-            const int ks = (int)((o >> 6) % NKX);
-            const int jt = (int)((o >> 6) / NKX);
+            int l, ks, jt;
+            if (NKX % 4 == 0) {                      // [JT][NKX/4][64][4]
+                const int s = (int)(o & 3);
+                l = (int)((o >> 2) & 63);
+                const int k4 = (int)((o >> 8) % (NKX / 4));
+                jt = (int)((o >> 8) / (NKX / 4));
+                ks = 4 * k4 + s;
+            } else {                                 // [JT][NKX][64]
+                l = (int)(o & 63);
+                ks = (int)((o >> 6) % NKX);
+                jt = (int)((o >> 6) / NKX);
+            }
             const int j = 16 * jt + (l & 15);
             const int k = (l >> 4) * NKX + ks;
             v = (j < R && k < F) ? w_ih[(long long)j * F + k] : 0.f;

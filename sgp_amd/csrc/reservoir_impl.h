@@ -25,7 +25,8 @@ using sgp::f32x4;
 
 // ---- packed layout (floats) ---------------------------------------------------------------
 //   bias  [JT][4 q][4 r]                      = b[16 jt + 4 q + r]
-//   Wx    [JT][NKX][64 lanes]                 = W_ih[16 jt + (l&15)][(l>>4) * NKX + ks]
+//   Wx    [JT][NKX/4][64 lanes][4]            = W_ih[16 jt + (l&15)][(l>>4) * NKX + ks], ks = 4 k4 + s
+//         ([JT][NKX][64 lanes] when NKX < 4): one 16-byte read per lane serves 4 MFMAs
 //   Wh    [JT][JT kb][64 lanes][4 s]          = W_hh[16 jt + (l&15)][16 kb + 4 (l>>4) + s]
 // (zero where the index runs past R or F).
 __host__ __device__ constexpr long long packed_floats(int JT, int NKX) {
@@ -163,12 +164,25 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
                 }
             }
             // input part
+            if constexpr (NKX % 4 == 0) {
 #pragma unroll
-            for (int ks = 0; ks < NKX; ++ks) {
+                for (int k4 = 0; k4 < NKX / 4; ++k4) {
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt)
-                    acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane], xr[ks],
-                                                                   acc[jt], 0, 0, 0);
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wx_t + ((jt * (NKX / 4) + k4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xr[4 * k4 + s], acc[jt], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane], xr[ks],
+                                                                       acc[jt], 0, 0, 0);
+                }
             }
             // activation
             if (a.act == SGP_ACT_TANH) {
@@ -336,12 +350,25 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
                 for (int w = 0; w < JW; ++w)
                     acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[w][s], h[kb][s], acc[w], 0, 0, 0);
         }
+        if constexpr (NKX % 4 == 0) {
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks)
+            for (int k4 = 0; k4 < NKX / 4; ++k4)
 #pragma unroll
-            for (int w = 0; w < JW; ++w)
-                acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[((wave * JW + w) * NKX + ks) * 64 + lane],
-                                                               xr[ks], acc[w], 0, 0, 0);
+                for (int w = 0; w < JW; ++w) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(
+                        wx_t + (((wave * JW + w) * (NKX / 4) + k4) * 64 + lane) * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xr[4 * k4 + s], acc[w], 0, 0, 0);
+                }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks)
+#pragma unroll
+                for (int w = 0; w < JW; ++w)
+                    acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[((wave * JW + w) * NKX + ks) * 64 + lane],
+                                                                   xr[ks], acc[w], 0, 0, 0);
+        }
         if (a.act == SGP_ACT_TANH) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)

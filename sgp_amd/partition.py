@@ -162,12 +162,15 @@ class PartitionedSpatial:
     compute at 8 GPUs; hidden behind it, scaling stays close to the compute curve."""
 
     def __init__(self, blocks: List[LocalBlock], receptive_field, global_attr, n_total,
-                 group=None, ops=HipOps, n_chunks=4):
+                 group=None, ops=HipOps, n_chunks=4, force_collectives=False):
         self.blocks = blocks                       # forward (+ backward) local blocks
         self.k, self.global_attr, self.n_total = receptive_field, global_attr, n_total
         self.group, self.ops = group, ops
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.n_chunks = max(1, int(n_chunks))
+        # run the exchange / reduction even on a one-rank group (self-test of the RCCL plumbing
+        # on a single-GPU box: a collective over one rank is valid and moves nothing)
+        self._dist = self.world_size > 1 or (force_collectives and dist.is_initialized())
         self._xchg = {}
         self._comm_stream = None
 
@@ -187,7 +190,7 @@ class PartitionedSpatial:
                 s = 1 + d * self.k + h
                 dst = out[:, :, s * feat:(s + 1) * feat]
                 # every rank enters the collective, even one whose block has no halo
-                halo = self._exchange(d, 0)(src) if self.world_size > 1 else None
+                halo = self._exchange(d, 0)(src) if self._dist else None
                 self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
                 src = dst
 
@@ -226,14 +229,14 @@ class PartitionedSpatial:
         comm.wait_stream(main)
 
     def encode_into(self, out, feat):
-        if self.world_size > 1 and out.is_cuda and self.n_chunks > 1 and out.shape[0] >= 8:
+        if self._dist and out.is_cuda and self.n_chunks > 1 and out.shape[0] >= 8:
             self._hops_pipelined(out, feat)
         else:
             self._hops_serial(out, feat)
         if self.global_attr:
             p = self.num_blocks() - 1
             sums = self.ops.node_sums(out[:, :, :feat])
-            if self.world_size > 1:
+            if self._dist:
                 if sums.is_cuda and dist.get_backend(self.group) == "gloo":
                     s_cpu = sums.cpu()
                     dist.all_reduce(s_cpu, op=dist.ReduceOp.SUM, group=self.group)
@@ -246,7 +249,7 @@ class PartitionedSpatial:
 
 def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
                              rank=None, world_size=None, group=None, ops=HipOps,
-                             balance="rows", n_chunks=4):
+                             balance="rows", n_chunks=4, force_collectives=False):
     """Split the forward (and backward) global operators for this rank."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
@@ -255,4 +258,4 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
                               ops_global[0].rowptr.numpy() if balance == "nnz" else None)
     blocks = [split_operator(op, bounds, rank) for op in ops_global]
     return PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
-                              n_chunks=n_chunks), bounds
+                              n_chunks=n_chunks, force_collectives=force_collectives), bounds

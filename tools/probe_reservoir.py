@@ -1,7 +1,10 @@
+"""Reservoir layer timings on the large-N shapes (target line and C5), optional activation sweep."""
 import os, sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sgp_amd
 from sgp_amd import hip
+
+
 def timeit(fn, n=3):
     fn(); torch.cuda.synchronize()
     a, b = hip.Event(), hip.Event()
@@ -9,17 +12,13 @@ def timeit(fn, n=3):
     for _ in range(n): fn()
     b.record()
     return a.elapsed_ms(b) / n
-N, T = 100000, 256
-for act in ("tanh", "relu", "identity"):
-    for (F, R) in [(64, 64), (3, 64)]:
-        try:
-            res = sgp_amd.Reservoir(F, R, activation=act)
-        except Exception as e:
-            print(act, "ctor:", e); continue
+
+
+N = 100000
+for (F, R, T) in [(64, 64, 256), (3, 64, 256), (128, 256, 64), (128, 128, 128)]:
+    for act in os.environ.get("SGP_ACTS", "tanh").split(","):
+        res = sgp_amd.Reservoir(F, R, activation=act)
         xin = torch.randn(T, N, F, device="cuda"); out = torch.empty(T, N, R, device="cuda")
-        try:
-            ms = timeit(lambda: res.encode_into(xin, out))
-        except Exception as e:
-            print(act, "run:", e); continue
+        ms = timeit(lambda: res.encode_into(xin, out))
         fl = N * T * 2 * R * (F + R)
-        print(f"{act} F={F} R={R}: {ms:.2f} ms {fl / ms / 1e9:.1f} TF/s", flush=True)
+        print(f"{act} F={F} R={R} T={T}: {ms:.2f} ms {fl / ms / 1e9:.1f} TF/s", flush=True)

@@ -252,7 +252,12 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         SGP_LDI(Ia, iq, 2); SGP_LDI(Ib, iq, 3);                                                 \
         int c = 0;                                                                              \
         for (; c + 3 < (NQ); c += 2) {                                                          \
+            /* priority toggles per quad (measured +2 %: the waves of a SIMD fall out of step, */ \
+            /* one is in its MFMA burst while another waits for operands); static priorities   */ \
+            /* by age and "most work left first" were 3-10 % SLOWER than the default           */ \
+            __builtin_amdgcn_s_setprio(2);                                                      \
             SGP_BODY_L(Wa, Xa, Ia, wq, iq, 0)                                                   \
+            __builtin_amdgcn_s_setprio(0);                                                      \
             SGP_BODY_L(Wb, Xb, Ib, wq, iq, 1)                                                   \
             wq += 512; iq += 128;                                                               \
             asm volatile("" : "+v"(wq), "+v"(iq));                                              \

@@ -245,6 +245,235 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
 
 constexpr int kLdsLimit = 160 * 1024;
 
+// ---- wide reservoirs (R = 256): weights do not fit the LDS, stream them THROUGH it ----------
+// One workgroup = 4 waves (one per SIMD), each wave owns up to 2 node tiles for all T steps.
+// The packed weights of a step are cut into blocks of 16 KB -- the fragments of all JT output
+// tiles for one k-block of W_hh (JT blocks), then for 4 input k-steps of W_ih (NKX/4 blocks) --
+// and the 4 waves fetch every block ONCE per workgroup by LDS-DMA (each wave 4 pieces of 1 KiB)
+// into a ring of 4 slots, two blocks ahead of the one being consumed; all 8 node tiles of the
+// workgroup then read it with ds_read_b128.  Before, every wave pulled its own copy of the
+// 384 KB through L1/L2 each step (4x the traffic, one wave per SIMD to hide it).
+template <int I> struct IntC { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(IntC<B>{}); static_for<B + 1, E>(f); }
+}
+
+__device__ __forceinline__ void res_dma16(const void* sbase, unsigned voff, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
+}
+
+template <int JT, int NKX, bool XVEC, bool OVEC>
+__global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
+    static_assert(JT % 4 == 0 && NKX % 4 == 0, "stream kernel: 4 pieces per wave, 16-byte input fragments");
+    constexpr int NT = 2;
+    constexpr int NB = JT + NKX / 4;                     // blocks per step
+    constexpr int SLOT = JT * 1024;                      // bytes per block
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bias_l = lds + 4 * SLOT / 4;                  // after the 4 ring slots
+    for (int i = threadIdx.x; i < JT * 16; i += 256) bias_l[i] = a.wp[i];
+    const float* wx = a.wp + JT * 16;
+    const float* wh = wx + JT * NKX * 64;
+
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // tile assignment (host: launch_stream): full workgroups own 8 tiles, the tail ones 4
+    const int full = a.tiles_per_wave;                   // number of workgroups with 2 tiles per wave
+    int tile0, tile1;
+    if ((int)blockIdx.x < full) { tile0 = ((int)blockIdx.x * 4 + wv) * 2; tile1 = tile0 + 2; }
+    else { tile0 = full * 8 + ((int)blockIdx.x - full) * 4 + wv; tile1 = tile0 + 1; }
+    tile1 = min(tile1, a.n_tiles);
+
+    int node[NT];
+    bool ok[NT];
+    f32x4 h[NT][JT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        node[i] = (tile0 + i) * 16 + n_in;
+        ok[i] = (tile0 + i) < tile1 && node[i] < a.N;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float hv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.h_state && ok[i]) {
+                const int j0 = 16 * jt + 4 * q;
+                const float* hp = a.h_state + (long long)node[i] * a.R + j0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    hv[r] = hp[r];
+            }
+            h[i][jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
+        }
+    }
+    const bool two = tile0 + 1 < tile1;                  // wave-uniform: second tile present
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned voff = (unsigned)lane * 16u;
+    // block b of a step -> its 4 pieces of this wave (jt = 4 wv .. 4 wv + 3).  The two base
+    // pointers are re-laundered every call so that the compiler forms the 96 piece addresses of a
+    // step with scalar adds on the spot instead of keeping them all in (spilled) SGPRs.
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(4 * wv) * 1024u);
+    const float* wh_w = wh + (long long)(4 * wv) * JT * 256;
+    const float* wx_w = wx + (long long)(4 * wv) * (NKX / 4) * 256;
+    auto fetch = [&](int b) {
+        const float* hb = wh_w;
+        const float* xb = wx_w;
+        unsigned l0 = lds_w;
+        asm volatile("" : "+s"(hb), "+s"(xb), "+s"(l0));
+        const unsigned slot = l0 + (unsigned)(b & 3) * SLOT;
+#pragma unroll
+        for (int pjt = 0; pjt < 4; ++pjt) {
+            const float* src = b < JT ? hb + (pjt * JT + b) * 256
+                                      : xb + (pjt * (NKX / 4) + (b - JT)) * 256;
+            res_dma16(src, voff, slot + (unsigned)pjt * 1024u);
+        }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // initial-state loads retired (see above)
+    __syncthreads();
+    fetch(0);
+    fetch(1);
+
+    for (int t = 0; t < a.T; ++t) {
+        float xr[NT][NKX];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
+            if constexpr (XVEC) {
+#pragma unroll
+                for (int k4 = 0; k4 < NKX / 4; ++k4) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[i]) v = *reinterpret_cast<const f32x4*>(xp + 4 * k4);   // F == 4 NKX (host check)
+                    xr[i][4 * k4 + 0] = v.x; xr[i][4 * k4 + 1] = v.y;
+                    xr[i][4 * k4 + 2] = v.z; xr[i][4 * k4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks)
+                    xr[i][ks] = ok[i] ? xp[ks] : 0.f;
+            }
+        }
+        f32x4 acc[NT][JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + jt * 16 + q * 4);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i][jt] = bv;
+        }
+        // (compile-time block index: h[.][b] and xr[.][ks] must be register names, a runtime
+        // loop here turns both arrays into scratch memory)
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            // two blocks ahead (the sequence repeats every step); slot (b + 2) & 3 was last read
+            // as block b - 2, which every wave finished before it passed the previous barrier
+            fetch((b + 2) % NB);
+            // block b: 4 pieces issued two fetches ago.  Once per step everything is drained
+            // (the input-row loads and state stores of the step boundary share the counter).
+            if constexpr (b == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            const float* slot = lds + (b & 3) * (SLOT / 4);
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const f32x4 wf = *reinterpret_cast<const f32x4*>(slot + (jt * 64 + lane) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    if constexpr (b < JT) {
+                        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[0][b][s], acc[0][jt], 0, 0, 0);
+                        if (two)
+                            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[1][b][s], acc[1][jt], 0, 0, 0);
+                    } else {
+                        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[0][4 * (b - JT) + s], acc[0][jt], 0, 0, 0);
+                        if (two)
+                            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[1][4 * (b - JT) + s], acc[1][jt], 0, 0, 0);
+                    }
+                }
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (i == 1 && !two) continue;
+            if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_f32(acc[i][jt][r]);
+            } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+            } else if (a.act == SGP_ACT_SELF_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss = fmaf(acc[i][jt][r], acc[i][jt][r], ss);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] *= inv;
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[i][jt][r] = a.one_minus_alpha * h[i][jt][r] + a.alpha * acc[i][jt][r];
+                const int j0 = 16 * jt + 4 * q;
+                if (ok[i]) {                                  // R == 16 JT (host check)
+                    float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
+                    if constexpr (OVEC) {
+                        *reinterpret_cast<f32x4*>(op) = h[i][jt];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) op[r] = h[i][jt][r];
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two blocks fetched ahead of the end
+    if (a.h_state) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[i]) a.h_state[(long long)node[i] * a.R + j0 + r] = h[i][jt][r];
+            }
+    }
+}
+
+template <int JT, int NKX>
+int launch_stream(ResArgs a, hipStream_t s) {
+    a.n_tiles = (a.N + 15) / 16;
+    // full rounds of 256 workgroups x 8 tiles; what is left gets one tile per wave if that is
+    // enough to hold it, so the last (partial) round costs half a round
+    const int per_round = 256 * 8;
+    int full = (a.n_tiles / per_round) * 256;
+    int rest = a.n_tiles - full * 8;
+    int tail_wgs;
+    if (rest > 1024) { full += (rest + 7) / 8; tail_wgs = 0; }
+    else tail_wgs = (rest + 3) / 4;
+    a.tiles_per_wave = full;
+    const bool xv = (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x);
+    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+    void (*kern)(ResArgs);
+    if (xv && ov) kern = reservoir_layer_stream<JT, NKX, true, true>;
+    else if (ov) kern = reservoir_layer_stream<JT, NKX, false, true>;
+    else kern = reservoir_layer_stream<JT, NKX, false, false>;
+    const int bytes = 4 * JT * 1024 + JT * 16 * 4;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(full + tail_wgs), dim3(256), (size_t)bytes, s, a);
+    return sgp::check_launch("reservoir_layer_stream");
+}
+
+
 // ---- small-N variant: one node tile per workgroup, the j-tiles split over its 4 waves -------
 // With a few hundred nodes (METR-LA 207, PEMS-BAY 325) there are only a dozen node tiles, and a
 // single wave stepping all JT output tiles is a serial chain of JT*(4*JT+NKX) MFMAs per time
@@ -484,6 +713,10 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
     }
     if constexpr (JT <= 4) {
         if (n_tiles > 4096) return launch_layer<JT, NKX, 2>(a, s);
+    }
+    if constexpr (packed_floats(JT, NKX) * 4 > kLdsLimit && JT % 4 == 0 && NKX % 4 == 0) {
+        // (exact widths: the stream kernel carries no feature masks)
+        if (n_tiles >= 2048 && a.F == 4 * NKX && a.R == 16 * JT) return launch_stream<JT, NKX>(a, s);
     }
     return launch_layer<JT, NKX, 1>(a, s);
 }

@@ -183,6 +183,42 @@ def test_reservoir_long_sequence(n, f, r, L):
     assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize("act", ["tanh", "relu", "self_norm"])
+def test_reservoir_wide_streamed_weights(act):
+    """C5's layer shape (F = 128, R = 256: 384 KB of weights, more than the LDS) at a node count
+    that takes the kernel which streams the weights through LDS once per workgroup (full
+    workgroups with two node tiles per wave AND the half-filled tail ones), against the oracle;
+    then the same sequence in two time chunks with the state carried on the device."""
+    torch.manual_seed(5)
+    n, t, f, r = 2048 * 16 + 16 * 37 + 5, 10, 128, 256
+    res = sgp_amd.Reservoir(f, r, num_layers=1, leaking_rate=0.8, spectral_radius=0.9, density=0.7,
+                            activation=act)
+    x = torch.randn(t, n, f)
+    xg = x.cuda()
+    out = torch.empty(t, n, r, device="cuda")
+    res.encode_into(xg, out)
+    idx = torch.cat([torch.arange(0, 64), torch.arange(16 * 1000, 16 * 1000 + 48),
+                     torch.arange(n - 700, n)])                    # full, middle and tail tiles
+    ref = O.reservoir_forward(x[:, idx], layers_of(res), act)
+    got = out[:, idx].cpu()
+    if act == "relu":
+        # unbounded activation, 384-term dot products of O(10) states: judge both fp32 results by
+        # their distance to the fp64 evaluation instead of a fixed absolute tolerance
+        ref64 = O.reservoir_forward(x[:, idx], layers_of(res), act, dtype=torch.float64)
+        e_gpu = float((got.double() - ref64).abs().max())
+        e_cpu = float((ref.double() - ref64).abs().max())
+        assert e_gpu <= 2 * e_cpu + 1e-6, (e_gpu, e_cpu)
+        assert O.rel_fro(got, ref) <= 1e-5
+    else:
+        close(got, ref)
+    state = torch.zeros(1, n, r, device="cuda")
+    out2 = torch.empty_like(out)
+    res.encode_into(xg[:4], out2[:4], state)
+    res.encode_into(xg[4:], out2[4:], state)
+    close(out2, out, rtol=1e-6, atol=1e-6)
+    close(state[0], out[-1], rtol=1e-6, atol=1e-6)
+
+
 def test_reservoir_state_carry_equals_one_shot():
     torch.manual_seed(1)
     res = sgp_amd.Reservoir(4, 32, num_layers=2, alpha_decay=True)

@@ -245,6 +245,7 @@ __global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArg
 
 constexpr int kLdsLimit = 160 * 1024;
 
+#ifdef SGP_RES_STREAM_TU
 // ---- wide reservoirs (R = 256): weights do not fit the LDS, stream them THROUGH it ----------
 // One workgroup = 4 waves (one per SIMD), each wave owns up to 2 node tiles for all T steps.
 // The packed weights of a step are cut into blocks of 16 KB -- the fragments of all JT output
@@ -270,6 +271,8 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     constexpr int NT = 2;
     constexpr int NB = JT + NKX / 4;                     // blocks per step
     constexpr int SLOT = JT * 1024;                      // bytes per block
+    constexpr int PPW = JT / 4;                          // 1-KiB pieces of a block per wave
+    static_assert(PPW == 4 || PPW == 2, "stream kernel: 8 or 16 output tiles");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* bias_l = lds + 4 * SLOT / 4;                  // after the 4 ring slots
     for (int i = threadIdx.x; i < JT * 16; i += 256) bias_l[i] = a.wp[i];
@@ -309,12 +312,12 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     const bool two = tile0 + 1 < tile1;                  // wave-uniform: second tile present
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
     const unsigned voff = (unsigned)lane * 16u;
-    // block b of a step -> its 4 pieces of this wave (jt = 4 wv .. 4 wv + 3).  The two base
+    // block b of a step -> the PPW pieces of this wave (jt = PPW wv .. PPW wv + PPW - 1).  The two base
     // pointers are re-laundered every call so that the compiler forms the 96 piece addresses of a
     // step with scalar adds on the spot instead of keeping them all in (spilled) SGPRs.
-    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(4 * wv) * 1024u);
-    const float* wh_w = wh + (long long)(4 * wv) * JT * 256;
-    const float* wx_w = wx + (long long)(4 * wv) * (NKX / 4) * 256;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PPW * wv) * 1024u);
+    const float* wh_w = wh + (long long)(PPW * wv) * JT * 256;
+    const float* wx_w = wx + (long long)(PPW * wv) * (NKX / 4) * 256;
     auto fetch = [&](int b) {
         const float* hb = wh_w;
         const float* xb = wx_w;
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
         asm volatile("" : "+s"(hb), "+s"(xb), "+s"(l0));
         const unsigned slot = l0 + (unsigned)(b & 3) * SLOT;
 #pragma unroll
-        for (int pjt = 0; pjt < 4; ++pjt) {
+        for (int pjt = 0; pjt < PPW; ++pjt) {
             const float* src = b < JT ? hb + (pjt * JT + b) * 256
                                       : xb + (pjt * (NKX / 4) + (b - JT)) * 256;
             res_dma16(src, voff, slot + (unsigned)pjt * 1024u);
@@ -369,7 +372,8 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
             // block b: 4 pieces issued two fetches ago.  Once per step everything is drained
             // (the input-row loads and state stores of the step boundary share the counter).
             if constexpr (b == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             const float* slot = lds + (b & 3) * (SLOT / 4);
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
@@ -459,12 +463,7 @@ int launch_stream(ResArgs a, hipStream_t s) {
     if (rest > 1024) { full += (rest + 7) / 8; tail_wgs = 0; }
     else tail_wgs = (rest + 3) / 4;
     a.tiles_per_wave = full;
-    const bool xv = (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x);
-    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
-    void (*kern)(ResArgs);
-    if (xv && ov) kern = reservoir_layer_stream<JT, NKX, true, true>;
-    else if (ov) kern = reservoir_layer_stream<JT, NKX, false, true>;
-    else kern = reservoir_layer_stream<JT, NKX, false, false>;
+    void (*kern)(ResArgs) = reservoir_layer_stream<JT, NKX, true, true>;
     const int bytes = 4 * JT * 1024 + JT * 16 * 4;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -473,6 +472,8 @@ int launch_stream(ResArgs a, hipStream_t s) {
     return sgp::check_launch("reservoir_layer_stream");
 }
 
+
+#endif  // SGP_RES_STREAM_TU
 
 // ---- small-N variant: one node tile per workgroup, the j-tiles split over its 4 waves -------
 // With a few hundred nodes (METR-LA 207, PEMS-BAY 325) there are only a dozen node tiles, and a
@@ -695,6 +696,8 @@ int launch_layer(ResArgs a, hipStream_t s) {
     return sgp::check_launch("reservoir_layer");
 }
 
+template <int JT, int NKX> int launch_stream_ool(const ResArgs& a, hipStream_t s);   // reservoir_stream.hip
+
 template <int JT, int NKX>
 int launch_nt(const ResArgs& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
@@ -716,7 +719,9 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
     }
     if constexpr (packed_floats(JT, NKX) * 4 > kLdsLimit && JT % 4 == 0 && NKX % 4 == 0) {
         // (exact widths: the stream kernel carries no feature masks)
-        if (n_tiles >= 2048 && a.F == 4 * NKX && a.R == 16 * JT) return launch_stream<JT, NKX>(a, s);
+        const bool vec = (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x) &&
+                         (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+        if (n_tiles >= 2048 && a.F == 4 * NKX && a.R == 16 * JT && vec) return launch_stream_ool<JT, NKX>(a, s);
     }
     return launch_layer<JT, NKX, 1>(a, s);
 }

@@ -183,14 +183,15 @@ def test_reservoir_long_sequence(n, f, r, L):
     assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
 
 
-@pytest.mark.parametrize("act", ["tanh", "relu", "self_norm"])
-def test_reservoir_wide_streamed_weights(act):
+@pytest.mark.parametrize("act,f,r", [("tanh", 128, 256), ("relu", 128, 256), ("self_norm", 128, 256),
+                                     ("tanh", 256, 128)])
+def test_reservoir_wide_streamed_weights(act, f, r):
     """C5's layer shape (F = 128, R = 256: 384 KB of weights, more than the LDS) at a node count
     that takes the kernel which streams the weights through LDS once per workgroup (full
     workgroups with two node tiles per wave AND the half-filled tail ones), against the oracle;
     then the same sequence in two time chunks with the state carried on the device."""
     torch.manual_seed(5)
-    n, t, f, r = 2048 * 16 + 16 * 37 + 5, 10, 128, 256
+    n, t = 2048 * 16 + 16 * 37 + 5, 10
     res = sgp_amd.Reservoir(f, r, num_layers=1, leaking_rate=0.8, spectral_radius=0.9, density=0.7,
                             activation=act)
     x = torch.randn(t, n, f)

@@ -33,18 +33,16 @@ __host__ __device__ constexpr long long packed_floats(int JT, int NKX) {
     return (long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256;
 }
 
-// tanh to ~2 ulp: odd Taylor polynomial below 0.25, 1 - 2/(e^{2|x|}+1) above.
+// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): 6 VALU instructions, two of them quarter-rate
+// (v_exp_f32, v_rcp_f32).  fp32 MFMAs do not co-execute with VALU work on gfx950, so every
+// instruction here is matrix-pipe time: the odd-polynomial branch that used to serve |x| < 0.25
+// (10 more instructions on every value) bought relative accuracy near zero that the parity
+// criterion (absolute 1e-5, distance to fp64 of the order of the fp32 reference's own) does not
+// ask for; the absolute error of this form is ~3e-7 everywhere (tested).
 __device__ __forceinline__ float tanh_f32(float x) {
-    const float a = fabsf(x);
-    const float x2 = x * x;
-    float p = 62.f / 2835.f;
-    p = fmaf(p, x2, -17.f / 315.f);
-    p = fmaf(p, x2, 2.f / 15.f);
-    p = fmaf(p, x2, -1.f / 3.f);
-    p = fmaf(p * x2, x, x);
-    const float e = __expf(2.f * a);
-    const float big = copysignf(1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f), x);
-    return a < 0.25f ? p : big;
+    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390081777927f);    // e^{2|x|}
+    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+    return copysignf(t, x);
 }
 
 struct ResArgs {
@@ -65,7 +63,7 @@ constexpr int min_waves(int JT, int NT) { return JT <= 4 ? 4 : (JT <= 8 ? 2 : 1)
 // time switch, not a branch inside the time loop: with both paths in one loop body the compiler's
 // s_waitcnt bookkeeping merges their pending loads and serialises every step on vmcnt(0).
 template <int JT, int NKX, int NT, bool WLDS, bool XVEC, bool OVEC>
-__global__ __launch_bounds__(256, min_waves(JT, NT)) void reservoir_layer(ResArgs a) {
+__global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reservoir_layer(ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const float* wsrc = a.wp;
     if constexpr (WLDS) {
@@ -675,7 +673,12 @@ int launch_layer(ResArgs a, hipStream_t s) {
     if (a.n_tiles > 1024) {
         const int rounds = (a.n_tiles + 1024 * NT - 1) / (1024 * NT);
         const int n_waves = 1024 * rounds;
-        wpw = 4;
+        // Narrow reservoirs (<= 128 VGPRs): ONE 16-wave workgroup per CU, so that the waves that
+        // share a SIMD (w, w+4, w+8, w+12 of a workgroup) are consecutive in the tile deal and the
+        // busiest SIMD carries ceil(tiles per CU / 4) tiles.  With 4-wave workgroups the four
+        // co-resident workgroups of a CU are unrelated and some SIMD ends up with 4 x NT tiles
+        // (8 against an average of 6.1 on the target line).
+        wpw = JT <= 4 ? 16 : 4;
         grid = n_waves / wpw;
     }
     const bool xv = (NKX % 4 == 0) && (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x);

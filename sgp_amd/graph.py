@@ -152,6 +152,16 @@ class ShiftOperator:
                     limits = hip.tiled_limits(feat)
                 plan = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
                                        self.num_nodes, **limits)
+                # No locality in the node numbering (e.g. a k-NN graph of stations listed in
+                # file order): tile by a locality order computed from the graph itself.
+                poor = plan is None or plan.tile_rows < 32
+                if poor and self.num_cols == self.num_nodes and self.num_nodes >= 2048 and \
+                        self.nnz() >= 8 * self.num_nodes:
+                    order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
+                    alt = build_reordered_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                               self.num_nodes, order, **limits)
+                    if alt is not None and (plan is None or alt.tile_rows > plan.tile_rows):
+                        plan = alt
                 if plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
@@ -182,6 +192,11 @@ class ShiftOperator:
             raise NotImplementedError("no two-phase stream for this plan")
         self.last_kernel = "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
             "spmm_tiled" if plan is not None else "spmm_csr_rows")
+        if plan is not None and plan.reordered and not use_mfma:
+            if force == "tiled":
+                raise NotImplementedError("a reordered plan serves the row-group kernels only")
+            plan = None                       # generic CSR kernel
+            self.last_kernel = "spmm_csr_rows"
         if use_pipe:
             hip.spmm_pipe(plan, x, y, halo, self.num_nodes)
         elif use_mfma:
@@ -260,6 +275,7 @@ class TilePlan:
     max_tile_quads: int = 0
     rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
     pipe: Optional[dict] = None             # two-phase stream of sgp_spmm_pipe_f32 (build_phase_stream)
+    reordered: bool = False                 # tiles follow locality_order, not the row numbering
 
     def to(self, device):
         mv = lambda t: None if t is None else t.to(device)
@@ -269,7 +285,8 @@ class TilePlan:
                         self.erow.to(device), self.ecol.to(device), self.eval.to(device),
                         self.tile_rows, self.n_tiles, self.n_rows, self.max_union,
                         self.max_row_edges, mv(self.gptr), self.group_fill,
-                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap), pipe)
+                        mv(self.gidx), mv(self.gw), self.max_tile_quads, mv(self.rowmap), pipe,
+                        self.reordered)
 
 
 def tile_unions(rowptr, col, trow):
@@ -593,6 +610,71 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
                 gptr=gptr.astype(np.int32), gsup=gsup.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
                 max_tile_quads=max_tile_quads, max_union=int(upad.max(initial=0)),
                 phase_cost=phase_cost, rowmap=rowmap)
+
+
+def locality_order(rowptr, col, n):
+    """A node order with 2-D locality computed from the graph alone (no coordinates): hop
+    distances from two pairs of far-apart landmarks (each found by a double BFS sweep) act as two
+    axes, ``x = d(a, .) - d(b, .)``, ``y = d(c, .) - d(d, .)``, and the nodes are sorted by the
+    Morton code of ``(x, y)``.  For a geometric k-NN graph whose node labels are scrambled this
+    brings the distinct-column count of a 64-row tile to within ~6 % of the order by the true
+    coordinates (396 vs 372 staged rows at N = 100 000; 6 300 without reordering).  Six BFS
+    sweeps: ~11 s at nnz = 10^7, one-off per graph."""
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import dijkstra
+    from .synthetic import morton_order
+    adj = sp.csr_matrix((np.ones(col.size, np.float32), col.astype(np.int64), rowptr.astype(np.int64)),
+                        shape=(n, n))
+    adj = (adj + adj.T).tocsr()
+
+    def hops(src):
+        d = dijkstra(adj, directed=False, indices=int(src), unweighted=True)
+        finite = np.isfinite(d)
+        d[~finite] = (d[finite].max() if finite.any() else 0) + 1     # other components: far away
+        return d
+
+    da = hops(0)
+    a = int(np.argmax(da)); da = hops(a)
+    b = int(np.argmax(da)); db = hops(b)
+    c = int(np.argmax(np.minimum(da, db))); dc = hops(c)             # far from both ends of axis 1
+    d_ = int(np.argmax(dc)); dd = hops(d_)
+    xy = np.stack([da - db, dc - dd], 1).astype(np.float64)
+    xy -= xy.min(0)
+    xy /= np.maximum(xy.max(0), 1.0)
+    return morton_order(xy, bits=12)
+
+
+def build_reordered_plan(rowptr, col, val, n_rows, order, **limits):
+    """Tile plan of the operator with rows and columns renumbered by ``order`` (new id k = old id
+    ``order[k]``), expressed in the ORIGINAL ids: the kernels gather source rows through ``ucol``
+    and write output rows through ``rowmap``, so a tile need not be a run of consecutive rows and
+    no tensor is ever permuted.  (The DPP kernel addresses a tile's rows as ``row0 + r``: a
+    reordered plan serves the row-group kernels only.)"""
+    import scipy.sparse as sp
+    order = np.asarray(order, dtype=np.int64)
+    pos = np.empty(n_rows, dtype=np.int64)
+    pos[order] = np.arange(n_rows)
+    rows = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr))
+    a = sp.csr_matrix((np.asarray(val), (pos[rows], pos[np.asarray(col, dtype=np.int64)])),
+                      shape=(n_rows, n_rows))
+    a.sort_indices()
+    plan = build_tile_plan(a.indptr.astype(np.int64), a.indices.astype(np.int32), a.data.astype(np.float32),
+                           n_rows, **limits)
+    if plan is None or plan.gw is None:
+        return None
+    order32 = torch.from_numpy(order.astype(np.int32))
+
+    def back_rows(t):                       # row ids (-1 = empty slot) -> original ids
+        t = t.long()
+        return torch.where(t >= 0, order32[t.clamp_min(0)].long(), t).int()
+
+    plan.ucol = order32[plan.ucol.long()]
+    plan.rowmap = back_rows(plan.rowmap)
+    if plan.pipe is not None:
+        plan.pipe["ucol"] = order32[plan.pipe["ucol"].long()]
+        plan.pipe["rowmap"] = back_rows(plan.pipe["rowmap"])
+    plan.reordered = True
+    return plan
 
 
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,

@@ -563,6 +563,34 @@ def test_onthefly_supports_match_reference(name):
     close(apply_supports(x[0].cuda(), sup), z["full"][0])          # a single [N, F] frame
 
 
+def test_scrambled_node_labels_take_the_fast_path():
+    """Stations listed in file order (no locality in the numbering): the operator tiles by a
+    locality order computed from the graph and still runs the pipelined matrix-core kernel; the
+    tensors themselves are never permuted.  Encoder output == oracle on the scrambled graph."""
+    torch.manual_seed(21)
+    n, t, d = 5000, 5, 64
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=6)
+    perm = torch.randperm(n)
+    ei = perm[ei]
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    x = torch.randn(t, n, d)
+    y = torch.full((t, n, d), float("nan"), device="cuda")
+    op.propagate(x.cuda(), y)
+    assert op.last_kernel == "spmm_pipe" and op.tile_plan(d, torch.device("cuda")).reordered
+    close(y, dense_ref(op, x))
+    y2 = torch.empty_like(y)
+    op.propagate(x.cuda(), y2, force="csr")
+    close(y, y2, rtol=1e-6, atol=1e-6)
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=64, reservoir_layers=1, leaking_rate=0.9,
+                             spectral_radius=0.9, density=0.7, input_scaling=1., receptive_field=2,
+                             bidirectional=True, alpha_decay=False, global_attr=True)
+    xin = torch.randn(t, n, 3)
+    out = enc(xin.cuda(), ei, ew).cpu()
+    ref = O.sgp_encoder_forward(xin, ei, ew, layers_of(enc.reservoir), 2, bidirectional=True,
+                                global_attr=True, sparse=True)
+    close(out, ref)
+
+
 def test_properties_at_scale():
     """Size-independent checks on a graph too large for the dense oracle."""
     torch.manual_seed(8)

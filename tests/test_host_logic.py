@@ -122,6 +122,40 @@ def test_tile_plan_splits_oversized_tiles_and_gives_up_on_random_graphs():
                                  **LIMITS) is None
 
 
+def test_reordered_plan_for_graphs_without_locality_in_the_numbering():
+    """A geometric k-NN graph whose node labels are scrambled: the row numbering has no locality
+    (16-row tiles at best), the landmark order restores 64-row tiles, and the reordered plan --
+    expressed in the ORIGINAL ids through ucol / rowmap -- is exactly the same operator."""
+    n = 4000
+    ei, ew, _ = synthetic.knn_graph(n, 24, seed=3)
+    perm = np.random.default_rng(1).permutation(n)
+    op = graph.ShiftOperator.from_edges(torch.from_numpy(perm[ei.numpy()]), ew, n)
+    args = (op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), n)
+    plain = graph.build_tile_plan(*args, **LIMITS)
+    assert plain is None or plain.tile_rows < 32
+    order = graph.locality_order(op.rowptr.numpy(), op.col.numpy(), n)
+    assert sorted(order.tolist()) == list(range(n))
+    plan = graph.build_reordered_plan(*args, order, **LIMITS)
+    assert plan is not None and plan.reordered and plan.tile_rows == 64 and plan.max_union <= 448
+    ps = plan.pipe
+    gptr, gw, gidx = ps["gptr"].numpy(), ps["gw"].numpy(), ps["gidx"].numpy()
+    uptr, ucol, rowmap = ps["uptr"].numpy(), ps["ucol"].numpy(), ps["rowmap"].numpy()
+    a = np.zeros((n, n))
+    for tile in range(plan.n_tiles):
+        for g in range(16):
+            for qd in range(gptr[(tile * 16 + g) * 2], gptr[(tile * 16 + g) * 2 + 2]):
+                for cls in range(4):
+                    for sup in range(4):
+                        c = ucol[uptr[tile] + gidx[qd, cls, sup] // 256]
+                        for i in range(4):
+                            if gw[qd, cls, i, sup] != 0:
+                                a[rowmap[tile * 64 + g * 4 + i], c] += gw[qd, cls, i, sup]
+    assert np.array_equal(a.astype(np.float32), op.to_dense().numpy())
+    # every row is written exactly once
+    rows = rowmap[rowmap >= 0]
+    assert sorted(rows.tolist()) == list(range(n))
+
+
 def test_tile_plan_small_sparse_graph():
     ei, ew = synthetic.sparse_traffic_graph(207, 1515, seed=3)
     op = graph.ShiftOperator.from_edges(ei, ew, 207)

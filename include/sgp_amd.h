@@ -136,7 +136,9 @@ int32_t sgp_spmm_mfma_max_quads(void);
  * of the LDS stage by LDS-DMA (global_load_lds_dwordx4) while the matrix cores consume the other.
  * gsup[2 (16 k + g) + s] = ceil(columns of that range / 4): the kernel skips the padding of a
  * range's last quad in units of one super-step.  uptr / ucol list segment A first (padded to a
- * multiple of 4 entries), then segment B.  gidx / gw / rowmap as for sgp_spmm_mfma_f32.  Limits: sgp_spmm_pipe_max_union() staged rows
+ * multiple of 4 entries), then segment B.  gidx / rowmap as for sgp_spmm_mfma_f32; gw is stored
+ * [quad][q][super-step s][row i] (one float per lane: the MFMA of super-step s broadcasts block s
+ * of its class, cbsz = 2 / abid = s).  Limits: sgp_spmm_pipe_max_union() staged rows
  * per tile, sgp_spmm_pipe_max_quads() quads per tile. */
 int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
                       const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,

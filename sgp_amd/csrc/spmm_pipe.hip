@@ -145,14 +145,19 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     // as opaque integers: a read is "address register + small immediate", the loop advances the
     // registers -- otherwise the compiler rebuilds `lds + 0x1c000 + ...` with a VALU add per read.
     typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
-    typedef const __attribute__((address_space(3))) i32x4* lds_i4_t;
+    typedef const __attribute__((address_space(3))) float* lds_f1_t;
+    typedef const __attribute__((address_space(3))) unsigned* lds_u1_t;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
-    unsigned wA = lds0 + kStageBytes + gA * 256 + (q * 4 + (lane & 3)) * 16;
-    unsigned iA = lds0 + kStageBytes + tile_quads * 256 + gA * 64 + q * 16;
+    // weights: one float per lane and quad -- lane (q, b = li >> 2, i = li & 3) holds the weight of
+    // row i for class q's column in super-step b; the MFMA of super-step s takes it from block b = s
+    // of the class (cbsz = 2, abid = s).  Offsets: lane (q, s = li & 3) holds class q's staged-row
+    // offset of super-step s; the address add takes it from lane s of its quad (DPP quad_perm).
+    unsigned wA = lds0 + kStageBytes + gA * 256 + lane * 4;
+    unsigned iA = lds0 + kStageBytes + tile_quads * 256 + gA * 64 + q * 16 + (lane & 3) * 4;
     unsigned wB = wA + nA * 256;
     unsigned iB = iA + nA * 64;
     asm volatile("" : "+v"(wA), "+v"(iA), "+v"(wB), "+v"(iB));
-    const char* xmine = lds + li * 16;
+    const unsigned xmine = lds0 + li * 16;
     // debug timeline (ABL & 32): workgroup `dbg[0]` records s_memtime at 8 points of 4 steps
     auto stamp = [&](int t, int point) {
         if constexpr (ABL & 32) {
@@ -212,44 +217,50 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     // sources at issue) the same registers are reloaded with super-step s of quad c+2, so every
     // wave keeps two quads of LDS reads in flight and a wave that runs alone on its SIMD (the
     // tail of a phase) is not bound by the LDS latency.  The last two quads use the "tail" body.
-    f32x4 Wa, Wb, Xa[4], Xb[4];
-    i32x4 Ia, Ib;
-#define SGP_LDW(DST, WP, C) DST = *(lds_f4_t)((WP) + (C) * 256)
-#define SGP_LDI(DST, IP, C) DST = *(lds_i4_t)((IP) + (C) * 64)
-#define SGP_LD1(DST, OFF) DST = *reinterpret_cast<const f32x4*>(xmine + (OFF))
-#define SGP_LDX(X, I) SGP_LD1(X[0], (I).x); SGP_LD1(X[1], (I).y); SGP_LD1(X[2], (I).z); SGP_LD1(X[3], (I).w);
-#define SGP_SUPER(W, XV)                                                                        \
-    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.x, acc0, 0, 0, 0);                          \
-    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.y, acc1, 0, 0, 0);                          \
-    acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.z, acc2, 0, 0, 0);                          \
-    acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.w, acc3, 0, 0, 0);
+    float Wa, Wb;
+    f32x4 Xa[4], Xb[4];
+    unsigned Ia, Ib;
+#define SGP_LDW(DST, WP, C) DST = *(lds_f1_t)((WP) + (C) * 256)
+#define SGP_LDI(DST, IP, C) DST = *(lds_u1_t)((IP) + (C) * 64)
+#define SGP_QP(S) ((S) | ((S) << 2) | ((S) << 4) | ((S) << 6))
+#define SGP_LD1(DST, I, S) DST = *(lds_f4_t)(xmine + (unsigned)__builtin_amdgcn_update_dpp(0, (int)(I), SGP_QP(S), 0xf, 0xf, true))
+#define SGP_LDX(X, I) SGP_LD1(X[0], I, 0); SGP_LD1(X[1], I, 1); SGP_LD1(X[2], I, 2); SGP_LD1(X[3], I, 3);
+#define SGP_SUPER(W, XV, S)                                                                     \
+    acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.x, acc0, 2, S, 0);                          \
+    acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.y, acc1, 2, S, 0);                          \
+    acc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.z, acc2, 2, S, 0);                          \
+    acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.w, acc3, 2, S, 0);
 #define SGP_SG(MASK, N) __builtin_amdgcn_sched_group_barrier(MASK, N, 0);
     // tail body: 16 MFMAs, nothing to fetch
-#define SGP_BODY_T(W, X) SGP_SUPER(W.x, X[0]) SGP_SUPER(W.y, X[1]) SGP_SUPER(W.z, X[2]) SGP_SUPER(W.w, X[3])
+#define SGP_BODY_T(W, X) SGP_SUPER(W, X[0], 0) SGP_SUPER(W, X[1], 1) SGP_SUPER(W, X[2], 2) SGP_SUPER(W, X[3], 3)
     // long body of quad C: MFMAs of C, operand reloads for C+2, then W(C+2) and I(C+4)
 #define SGP_BODY_L(W, X, I, WP, IP, C)  /* C = 0 or 1: quad relative to the running pointers */ \
-    SGP_SUPER(W.x, X[0]) SGP_LD1(X[0], (I).x);                                                  \
-    SGP_SUPER(W.y, X[1]) SGP_LD1(X[1], (I).y);                                                  \
-    SGP_SUPER(W.z, X[2]) SGP_LD1(X[2], (I).z);                                                  \
-    SGP_SUPER(W.w, X[3]) SGP_LD1(X[3], (I).w);                                                  \
+    SGP_SUPER(W, X[0], 0) SGP_LD1(X[0], I, 0);                                                  \
+    SGP_SUPER(W, X[1], 1) SGP_LD1(X[1], I, 1);                                                  \
+    SGP_SUPER(W, X[2], 2) SGP_LD1(X[2], I, 2);                                                  \
+    SGP_SUPER(W, X[3], 3) SGP_LD1(X[3], I, 3);                                                  \
     SGP_LDW(W, WP, (C) + 2); SGP_LDI(I, IP, (C) + 4);                                           \
     SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 1)                         \
     SGP_SG(0x008, 4) SGP_SG(0x100, 1) SGP_SG(0x008, 4) SGP_SG(0x100, 3)
     // last quad of a range: only its first NS super-steps carry columns
 #define SGP_BODY_E(W, X, NS)                                                                    \
-    SGP_SUPER(W.x, X[0])                                                                        \
-    if ((NS) > 1) { SGP_SUPER(W.y, X[1])                                                        \
-        if ((NS) > 2) { SGP_SUPER(W.z, X[2])                                                    \
-            if ((NS) > 3) { SGP_SUPER(W.w, X[3]) } } }
-    // before the barrier (the stream is static): weights of quads 0, 1 and offsets of quads 0, 1
-#define SGP_PRE(WP, IP) SGP_LDI(Ia, IP, 0); SGP_LDI(Ib, IP, 1); SGP_LDW(Wa, WP, 0); SGP_LDW(Wb, WP, 1);
+    SGP_SUPER(W, X[0], 0)                                                                       \
+    if ((NS) > 1) { SGP_SUPER(W, X[1], 1)                                                       \
+        if ((NS) > 2) { SGP_SUPER(W, X[2], 2)                                                   \
+            if ((NS) > 3) { SGP_SUPER(W, X[3], 3) } } }
+    // before the barrier (the stream is static): offsets of quads 0, 1
+#define SGP_PRE(WP, IP) SGP_LDI(Ia, IP, 0); SGP_LDI(Ib, IP, 1);
     // one phase: quads 0 .. NQ-1 of the stream at (WP, IP), the last one NS super-steps long
 #define SGP_PHASE(WP0, IP0, NQ, NS)                                                             \
     if ((NQ) > 0 && !(ABL & 2)) {                                                               \
         unsigned wq = (WP0), iq = (IP0);                                                        \
-        SGP_LDX(Xa, Ia)                                                                         \
-        if ((NQ) > 1) { SGP_LDX(Xb, Ib) }                                                       \
-        SGP_LDI(Ia, iq, 2); SGP_LDI(Ib, iq, 3);                                                 \
+        /* issued in exactly the order of the steady state (X0-3, W, I per quad): hipcc's     */ \
+        /* s_waitcnt pass merges the loop entry with the back edge and takes the stricter     */ \
+        /* count -- with a different order here every iteration drained the LDS queue to one  */ \
+        /* outstanding read at its top.  (Quad 1's reads are issued even if the range has a   */ \
+        /* single quad: what they fetch is never used.)                                       */ \
+        SGP_LDX(Xa, Ia) SGP_LDW(Wa, wq, 0); SGP_LDI(Ia, iq, 2);                                 \
+        SGP_LDX(Xb, Ib) SGP_LDW(Wb, wq, 1); SGP_LDI(Ib, iq, 3);                                 \
         int c = 0;                                                                              \
         for (; c + 3 < (NQ); c += 2) {                                                          \
             /* priority toggles per quad (measured +2 %: the waves of a SIMD fall out of step, */ \
@@ -338,6 +349,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
 #undef SGP_SG
 #undef SGP_SUPER
 #undef SGP_LDX
+#undef SGP_QP
 #undef SGP_LD1
 #undef SGP_LDI
 #undef SGP_LDW

@@ -598,8 +598,9 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
     n_quads = int(gptr[-1])
     gidx = np.zeros((n_quads, 4, 4), dtype=np.int32)
     gidx[quad, cls, sup] = (stage_slot * 256).astype(np.int32)
-    gw = np.zeros((n_quads, 4, GROUP_ROWS, 4), dtype=np.float32)
-    gw[quad[inv], cls[inv], slot_in_group[row_of_edge], sup[inv]] = val
+    # [quad][class][super-step][row]: one float per lane of the wave (lane = 16 class + 4 sup + row)
+    gw = np.zeros((n_quads, 4, 4, GROUP_ROWS), dtype=np.float32)
+    gw[quad[inv], cls[inv], sup[inv], slot_in_group[row_of_edge]] = val
     fill = float(lcol.size) / max(1, int(gsup.sum()) * 4 * GROUP_ROWS)
     max_tile_quads = int(np.diff(gptr[::2 * GROUPS_PER_TILE]).max()) if n_tiles else 0
     rowmap = np.full(n_tiles * GROUP_ROWS * GROUPS_PER_TILE, -1, dtype=np.int32)

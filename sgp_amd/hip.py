@@ -12,7 +12,8 @@ import subprocess
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libsgp_amd.so")
+# SGP_AMD_LIB: developer override (ablation / experiment builds of tools/build_variant.sh)
+LIB_PATH = os.environ.get("SGP_AMD_LIB") or os.path.join(_CSRC, "libsgp_amd.so")
 
 c_i32, c_i64, c_f32, c_f64, c_p = (ctypes.c_int32, ctypes.c_int64,
                                    ctypes.c_float, ctypes.c_double,

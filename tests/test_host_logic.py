@@ -148,8 +148,8 @@ def test_reordered_plan_for_graphs_without_locality_in_the_numbering():
                     for sup in range(4):
                         c = ucol[uptr[tile] + gidx[qd, cls, sup] // 256]
                         for i in range(4):
-                            if gw[qd, cls, i, sup] != 0:
-                                a[rowmap[tile * 64 + g * 4 + i], c] += gw[qd, cls, i, sup]
+                            if gw[qd, cls, sup, i] != 0:
+                                a[rowmap[tile * 64 + g * 4 + i], c] += gw[qd, cls, sup, i]
     assert np.array_equal(a.astype(np.float32), op.to_dense().numpy())
     # every row is written exactly once
     rows = rowmap[rowmap >= 0]

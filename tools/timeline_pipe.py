@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("SGP_PIPE_ABL", "32")
 import numpy as np, torch
 from sgp_amd import graph, hip, synthetic
-N, T, D = 100000, 64, 64
+N, T, D = int(os.environ.get("SGP_PROBE_N", 100000)), int(os.environ.get("SGP_PROBE_T", 64)), 64
 ei, ew, _ = synthetic.knn_graph(N, 100)
 op = graph.ShiftOperator.from_edges(ei, ew, N)
 x = torch.randn(T, N, D, device="cuda"); y = torch.empty_like(x)

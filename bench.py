@@ -46,9 +46,9 @@ WORKLOADS = {
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 # Fabric-side bytes of one hop launch from rocprofv3 PMC passes of this very command
-# (profiles/r1/bench_target_summary.txt): WRITE_SIZE 2.56e7 KB + 2 x FETCH_SIZE 3.50e7 KB -- on
+# (profiles/r1/bench_target_summary.txt): WRITE_SIZE 2.56e7 KB + 2 x FETCH_SIZE 3.60e7 KB -- on
 # gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM).
-PROFILED_TRAFFIC = {"target": 2.56e7 * 1024 + 2 * 3.50e7 * 1024}
+PROFILED_TRAFFIC = {"target": 2.56e7 * 1024 + 2 * 3.60e7 * 1024}
 
 
 def build_graph(w):

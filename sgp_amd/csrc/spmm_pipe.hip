@@ -251,8 +251,8 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     // before the barrier (the stream is static): offsets of quads 0, 1
 #define SGP_PRE(WP, IP) SGP_LDI(Ia, IP, 0); SGP_LDI(Ib, IP, 1);
     // one phase: quads 0 .. NQ-1 of the stream at (WP, IP), the last one NS super-steps long
-#define SGP_PHASE(WP0, IP0, NQ, NS)                                                             \
-    if ((NQ) > 0 && !(ABL & 2)) {                                                               \
+#define SGP_PHASE(WP0, IP0, NQ, NS, MID)                                                        \
+    if (!((NQ) > 0 && !(ABL & 2))) { MID } else {                                               \
         unsigned wq = (WP0), iq = (IP0);                                                        \
         /* issued in exactly the order of the steady state (X0-3, W, I per quad): hipcc's     */ \
         /* s_waitcnt pass merges the loop entry with the back edge and takes the stricter     */ \
@@ -261,6 +261,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         /* single quad: what they fetch is never used.)                                       */ \
         SGP_LDX(Xa, Ia) SGP_LDW(Wa, wq, 0); SGP_LDI(Ia, iq, 2);                                 \
         SGP_LDX(Xb, Ib) SGP_LDW(Wb, wq, 1); SGP_LDI(Ib, iq, 3);                                 \
+        MID                                                                                     \
         int c = 0;                                                                              \
         for (; c + 3 < (NQ); c += 2) {                                                          \
             /* priority toggles per quad (measured +2 %: the waves of a SIMD fall out of step, */ \
@@ -287,11 +288,29 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     }
 
     float* y_row = a.Y + (long long)t_begin * a.ybs + (long long)(my_row < 0 ? 0 : my_row) * a.yrs + f_base + li * 4;
+    // sum the 4 column classes; class q keeps row q (see spmm.hip)
+#define SGP_FOLD(ACC, DST)                                                                       \
+    {                                                                                           \
+        auto p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.x), __float_as_uint(ACC.y), false, false); \
+        auto p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.z), __float_as_uint(ACC.w), false, false); \
+        const float r01 = __uint_as_float(p01[0]) + __uint_as_float(p01[1]);                    \
+        const float r23 = __uint_as_float(p23[0]) + __uint_as_float(p23[1]);                    \
+        auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r01), __float_as_uint(r23), false, false); \
+        DST = __uint_as_float(h[0]) + __uint_as_float(h[1]);                                    \
+    }
+    // result of the step held in the accumulators -> its row (streamed: nontemporal, so that it
+    // does not displace the staged rows other tiles of this XCD are about to re-read from L2)
+#define SGP_EMIT                                                                                 \
+    {                                                                                           \
+        f32x4 out;                                                                              \
+        SGP_FOLD(acc0, out.x) SGP_FOLD(acc1, out.y) SGP_FOLD(acc2, out.z) SGP_FOLD(acc3, out.w) \
+        if (my_row >= 0) __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(y_row));     \
+        y_row += a.ybs;                                                                         \
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f}; acc1 = acc0; acc2 = acc0; acc3 = acc0;                \
+    }
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
     for (int t = t_begin; t < t_end; ++t) {
-        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
         // ---- phase A: region A holds step t once every wave's pieces have landed
-        // (this wave's pieces of A(t) were retired before the store of step t-1 was issued, so
-        // the barrier does not wait for that store)
         SGP_PRE(wA, iA)
         stamp(t, 0);
         asm volatile("s_barrier" ::: "memory");
@@ -303,7 +322,9 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         const bool dma_first = wave >= 8;
         if (dma_first) dma_segment(x_step, h_step, piecesB);
         stamp(t, 2);
-        SGP_PHASE(wA, iA, nA, lastA)
+        // the fold + store of step t-1 sit UNDER the first operand reads of step t (the wave
+        // would wait for them anyway) instead of in front of the barrier every wave waits at
+        SGP_PHASE(wA, iA, nA, lastA, if (t > t_begin) SGP_EMIT)
         if (!dma_first) dma_segment(x_step, h_step, piecesB);
         // ---- phase B
         SGP_PRE(wB, iB)
@@ -313,34 +334,17 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         asm volatile("s_barrier" ::: "memory");
         stamp(t, 5);
         if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
-        SGP_PHASE(wB, iB, nB, lastB)
+        SGP_PHASE(wB, iB, nB, lastB, )
         if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         stamp(t, 6);
-
-        // sum the 4 column classes; class q keeps row q (see spmm.hip)
-        f32x4 out;
-#define SGP_FOLD(ACC, DST)                                                                       \
-        {                                                                                       \
-            auto p01 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.x), __float_as_uint(ACC.y), false, false); \
-            auto p23 = __builtin_amdgcn_permlane16_swap(__float_as_uint(ACC.z), __float_as_uint(ACC.w), false, false); \
-            const float r01 = __uint_as_float(p01[0]) + __uint_as_float(p01[1]);                \
-            const float r23 = __uint_as_float(p23[0]) + __uint_as_float(p23[1]);                \
-            auto h = __builtin_amdgcn_permlane32_swap(__float_as_uint(r01), __float_as_uint(r23), false, false); \
-            DST = __uint_as_float(h[0]) + __uint_as_float(h[1]);                                \
-        }
-        SGP_FOLD(acc0, out.x) SGP_FOLD(acc1, out.y) SGP_FOLD(acc2, out.z) SGP_FOLD(acc3, out.w)
-#undef SGP_FOLD
-        // retire this wave's DMA of A(t+1) BEFORE the store is issued, so that the next
-        // barrier's vmcnt(0) does not wait for the store that was issued a moment ago
+        // this wave's pieces of A(t+1) (and the store of step t-1) retired before the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(t, 7);
-        // streamed result: nontemporal, so that it does not displace the staged rows other tiles
-        // of this XCD are about to re-read from L2
-        if (my_row >= 0)
-            __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(y_row));
-        y_row += a.ybs;
         x_step += x_inc; h_step += h_inc;
     }
+    SGP_EMIT
+#undef SGP_EMIT
+#undef SGP_FOLD
 #undef SGP_PRE
 #undef SGP_PHASE
 #undef SGP_BODY_L

@@ -19,7 +19,7 @@ def timeit(fn, n=3):
 def main():
     only_spmm = len(sys.argv) > 1 and sys.argv[1] == "spmm"
     N, T, D, K = int(os.environ.get("SGP_PROBE_N", 100000)), 256, 64, 4
-    ei, ew, _ = synthetic.knn_graph(N, 100)
+    ei, ew, _ = synthetic.knn_graph(N, int(os.environ.get("SGP_PROBE_K", 100)))
     op = graph.ShiftOperator.from_edges(ei, ew, N)
     x = torch.randn(T, N, D, device="cuda")
     y = torch.empty_like(x)

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(1024) void quad_loop(float* sink, unsigned long lon
     acc3 = __builtin_amdgcn_mfma_f32_4x4x1f32(W, XV.w, acc3, 2, S, 0); }         \
     else { asm volatile("" :: "v"(XV.x), "v"(XV.y), "v"(XV.z), "v"(XV.w), "v"(W)); }
 #define SG(M, N) __builtin_amdgcn_sched_group_barrier(M, N, 0);
+#define LDXA(X, A) X[0] = *(lds_f4_t)(A[0]); X[1] = *(lds_f4_t)(A[1]); X[2] = *(lds_f4_t)(A[2]); X[3] = *(lds_f4_t)(A[3]);
 #define BODY_T(W, X) SUPER(W, X[0], 0) SUPER(W, X[1], 1) SUPER(W, X[2], 2) SUPER(W, X[3], 3)
 #define BODY_L(W, X, I, C)                                                       \
     SUPER(W, X[0], 0) LD1(X[0], I, 0) SUPER(W, X[1], 1) LD1(X[1], I, 1)          \
@@ -58,7 +59,24 @@ __global__ __launch_bounds__(1024) void quad_loop(float* sink, unsigned long lon
     LDW(W, (C) + 2); LDI(I, (C) + 4);                                            \
     SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 3)
     unsigned long long t0 = __builtin_readcyclecounter();
-    if (VARIANT & 16) {
+    if (VARIANT & 64) {
+        // single operand buffer, addresses in registers (no VALU, no offset reads): super-step s of
+        // the next quad is requested right after the MFMAs of super-step s have issued
+        LDXA(Xa, xfix) LDW(Wa, 0); LDW(Wb, 1);
+#define QUAD1(W, C)                                                               \
+                SUPER(W, Xa[0], 0) Xa[0] = *(lds_f4_t)(xfix[0]);                  \
+                SUPER(W, Xa[1], 1) Xa[1] = *(lds_f4_t)(xfix[1]);                  \
+                SUPER(W, Xa[2], 2) Xa[2] = *(lds_f4_t)(xfix[2]);                  \
+                SUPER(W, Xa[3], 3) Xa[3] = *(lds_f4_t)(xfix[3]);                  \
+                LDW(W, (C) + 2);                                                  \
+                SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 1) SG(0x008, 4) SG(0x100, 2)
+        for (int r = 0; r < rounds; ++r) {
+            for (int c = 0; c < n_quads; c += 2) {
+                QUAD1(Wa, c)
+                QUAD1(Wb, c + 1)
+            }
+        }
+    } else if (VARIANT & 16) {
         // address adds hoisted out of the MFMA stream: all offsets of a 4-quad phase are read and
         // added up front, the quads read their operands through ready-made address registers
         unsigned I0, I1, I2, I3, A0[4], A1[4], A2[4], A3[4];
@@ -67,7 +85,6 @@ __global__ __launch_bounds__(1024) void quad_loop(float* sink, unsigned long lon
                    A[1] = xmine + (unsigned)__builtin_amdgcn_update_dpp(0, (int)(I), QP(1), 0xf, 0xf, true); \
                    A[2] = xmine + (unsigned)__builtin_amdgcn_update_dpp(0, (int)(I), QP(2), 0xf, 0xf, true); \
                    A[3] = xmine + (unsigned)__builtin_amdgcn_update_dpp(0, (int)(I), QP(3), 0xf, 0xf, true);
-#define LDXA(X, A) X[0] = *(lds_f4_t)(A[0]); X[1] = *(lds_f4_t)(A[1]); X[2] = *(lds_f4_t)(A[2]); X[3] = *(lds_f4_t)(A[3]);
 #define BODY_LA(W, X, A, C)                                                      \
     SUPER(W, X[0], 0) X[0] = *(lds_f4_t)(A[0]); SUPER(W, X[1], 1) X[1] = *(lds_f4_t)(A[1]); \
     SUPER(W, X[2], 2) X[2] = *(lds_f4_t)(A[2]); SUPER(W, X[3], 3) X[3] = *(lds_f4_t)(A[3]); \
@@ -133,6 +150,9 @@ int main() {
         run<2>("no X reads", 1024, nq);
         run<6>("MFMA only", 1024, nq);
         run<8>("no MFMA", 1024, nq);
+        run<64>("single buffer, addresses in registers", 1024, nq);
+        run<64>("single buffer, addr regs, 2 waves/SIMD", 512, nq);
+        run<64>("single buffer, addr regs, 1 wave/SIMD", 256, nq);
         run<32>("plain v_add, offsets 4 ints per lane", 1024, nq);
         run<16>("adds hoisted (4-quad phases)", 1024, nq);
         run<16>("adds hoisted, 2 waves/SIMD", 512, nq);

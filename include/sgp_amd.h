@@ -152,6 +152,32 @@ int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* u
                       sgp_stream_t stream);
 int32_t sgp_spmm_pipe_max_union(void);
 int32_t sgp_spmm_pipe_max_quads(void);
+/* Launch shape of sgp_spmm_pipe_f32 (process-wide; a negative / zero argument keeps the setting):
+ * persist 0 = one workgroup per (tile, 32-step chunk); 1 = one workgroup per CU, the workgroups of
+ * an XCD walk (32 neighbouring tiles, unit_steps time steps) units together; 2 = 1 + a bounded
+ * rendezvous of the XCD's workgroups at every unit start.  Results are identical in every mode. */
+int sgp_spmm_pipe_tune(int32_t persist, int32_t unit_steps);
+
+/* Register-resident form of sgp_spmm_pipe_f32: same plan arrays and arithmetic (bit-identical
+ * results), but a group's weights and the per-lane LDS addresses of its staged rows are loaded
+ * once per workgroup into VGPRs, so a super-step is one ds_read_b128 + 4 MFMAs with no VALU
+ * address arithmetic and no stream reads from LDS (ranges longer than 20 super-steps continue from
+ * an LDS copy of the stream).  Limits as for sgp_spmm_pipe_f32: sgp_spmm_res_max_union() staged
+ * rows and sgp_spmm_res_max_quads() quads per tile.  sgp_spmm_res_tune(cfg): 0 = 16 waves x 1 group
+ * per workgroup, 1 = 8 waves x 2 groups (process-wide). */
+int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+                     const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
+                     const int32_t* rowmap,
+                     int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
+                     const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                     const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                     int32_t n_own,
+                     float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                     int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                     sgp_stream_t stream);
+int32_t sgp_spmm_res_max_union(void);
+int32_t sgp_spmm_res_max_quads(void);
+int sgp_spmm_res_tune(int32_t cfg);
 
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and

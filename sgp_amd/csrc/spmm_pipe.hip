@@ -46,6 +46,7 @@ struct PipeArgs {
     float* Y; long long yrs, ybs;
     int n_rows, batch, feat;
     int t_chunk, n_tchunks;
+    unsigned* sync;                        // persistent mode: arrival counters [grid.y][8] (zeroed per launch) or null
     unsigned* dbg;                         // timeline stamps (ablation builds only)
 };
 
@@ -72,21 +73,54 @@ __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off)
                  :: "v"(vaddr), "s"(lds_off) : "memory");
 }
 
-template <bool HALO, int ABL = 0>
+// PERSIST: one workgroup per CU for the whole launch.  The workgroups of an XCD (block ids b with
+// the same b % 8 -- a speed assumption only, any placement computes the same result) walk "units"
+// together: unit = (32 consecutive tiles, one time chunk), workgroup rank r takes tile 32 s + r.
+// Neighbouring tiles stage overlapping source rows, so when the XCD's CUs sit on the same time
+// steps a row crosses the fabric once per XCD instead of once per tile that uses it.
+template <bool HALO, int ABL = 0, bool PERSIST = false>
 __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    // XCD-aware decode (workgroup ids are dealt round-robin to the 8 XCDs -- a speed assumption
-    // only): consecutive ids on one XCD = consecutive tiles of one time chunk, so the workgroups
-    // that share an L2 stage overlapping source rows of the same time steps.  (Measured without
-    // gain: every XCD owning 1/8 of the tiles with all XCDs walking the chunks together.)
-    const int nwg = a.n_tiles * a.n_tchunks;
-    const int orig = blockIdx.x;
-    const int qq = nwg >> 3, rr = nwg & 7, xcd = orig & 7;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (orig >> 3);
-    const int tile = wg % a.n_tiles;
-    const int tchunk = wg / a.n_tiles;
     const int f_base = blockIdx.y * 64;
+    const int xcd = blockIdx.x & 7, rank = blockIdx.x >> 3, n_ranks = gridDim.x >> 3;
+    const int n_super = (a.n_tiles + n_ranks - 1) / n_ranks;
+    const int n_units = PERSIST ? n_super * a.n_tchunks : 1;
+    const int unit0 = PERSIST ? (int)((long long)n_units * xcd / 8) : 0;
+    const int unit1 = PERSIST ? (int)((long long)n_units * (xcd + 1) / 8) : 1;
+  for (int unit = unit0; unit < unit1; ++unit) {
+    int wg, tile, tchunk;
+    if constexpr (PERSIST) {
+        wg = unit;
+        tile = (unit / a.n_tchunks) * n_ranks + rank;
+        tchunk = unit % a.n_tchunks;
+        __syncthreads();                                  // the previous unit's stream is no longer read
+        if (a.sync) {
+            // soft rendezvous of the XCD's workgroups at the start of a unit (bounded: a late or
+            // not yet resident workgroup only costs locality, never progress)
+            if (threadIdx.x == 0) {
+                unsigned* c = a.sync + blockIdx.y * 8 + xcd;
+                const unsigned want = (unsigned)(unit - unit0 + 1) * (unsigned)n_ranks;
+                __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int spin = 0; spin < 400; ++spin) {
+                    if (__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
+        if (tile >= a.n_tiles) continue;
+    } else {
+        // XCD-aware decode (workgroup ids are dealt round-robin to the 8 XCDs -- a speed assumption
+        // only): consecutive ids on one XCD = consecutive tiles of one time chunk, so the workgroups
+        // that share an L2 stage overlapping source rows of the same time steps.
+        const int nwg = a.n_tiles * a.n_tchunks;
+        const int orig = blockIdx.x;
+        const int qq = nwg >> 3, rr = nwg & 7, x8 = orig & 7;
+        wg = (x8 < rr ? x8 * (qq + 1) : rr * (qq + 1) + (x8 - rr) * qq) + (orig >> 3);
+        tile = wg % a.n_tiles;
+        tchunk = wg / a.n_tiles;
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,7 +134,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
 
     const int t_begin = tchunk * a.t_chunk;
     const int t_end = min(a.batch, t_begin + a.t_chunk);
-    if (t_begin >= t_end) return;
+    if (t_begin >= t_end) continue;
 
     // per-lane source of every staged row this lane feeds: byte offset from the step base
     unsigned voff[kPasses];
@@ -343,6 +377,7 @@ __global__ __launch_bounds__(1024) void spmm_pipe(PipeArgs a) {
         x_step += x_inc; h_step += h_inc;
     }
     SGP_EMIT
+  }   // unit
 #undef SGP_EMIT
 #undef SGP_FOLD
 #undef SGP_PRE
@@ -367,9 +402,41 @@ int pipe_chunk_cap() {
 
 unsigned pipe_grid(const PipeArgs& a) { return (unsigned)(a.n_tiles * a.n_tchunks); }
 
+int g_persist = -1, g_unit = -1;
+int pipe_persist_mode() {                                  // 0 off, 1 persistent, 2 + rendezvous per unit
+    if (g_persist < 0) { const char* e = getenv("SGP_SPMM_PERSIST"); g_persist = e ? atoi(e) : 0; }
+    return g_persist;
+}
+int pipe_unit_steps() {
+    if (g_unit < 0) { const char* e = getenv("SGP_SPMM_UNIT"); g_unit = e ? atoi(e) : 128; if (g_unit < 1) g_unit = 128; }
+    return g_unit;
+}
+unsigned* pipe_sync_buffer() {
+    static unsigned* p = nullptr;
+    if (!p) { if (hipMalloc(&p, 64 * 8 * sizeof(unsigned)) != hipSuccess) p = nullptr; }
+    return p;
+}
+
 template <bool HALO>
-int launch_pipe(const PipeArgs& a, hipStream_t s) {
+int launch_pipe(PipeArgs a, hipStream_t s) {
     const size_t lds_bytes = 160 * 1024;
+    if (pipe_persist_mode() > 0) {
+        auto kern = spmm_pipe<HALO, 0, true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return sgp::fail((int)e, "spmm_pipe: LDS opt-in: %s", hipGetErrorString(e));
+        const int tc = a.batch < pipe_unit_steps() ? a.batch : pipe_unit_steps();
+        a.t_chunk = tc;
+        a.n_tchunks = (a.batch + tc - 1) / tc;
+        a.sync = nullptr;
+        const int ny = a.feat / 64;
+        if (pipe_persist_mode() > 1 && ny <= 64 && pipe_sync_buffer()) {
+            a.sync = pipe_sync_buffer();
+            (void)hipMemsetAsync(a.sync, 0, (size_t)ny * 8 * sizeof(unsigned), s);
+        }
+        hipLaunchKernelGGL(kern, dim3(256, ny), dim3(1024), lds_bytes, s, a);
+        return sgp::check_launch("spmm_pipe");
+    }
 #ifdef SGP_ABLATION
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
@@ -408,6 +475,11 @@ extern "C" int sgp_spmm_pipe_debug_read(unsigned* host) {
 extern "C" {
 
 int32_t sgp_spmm_pipe_max_union(void) { return kPasses * 64; }
+int sgp_spmm_pipe_tune(int32_t persist, int32_t unit_steps) {
+    if (persist >= 0) g_persist = persist;
+    if (unit_steps > 0) g_unit = unit_steps;
+    return 0;
+}
 int32_t sgp_spmm_pipe_max_quads(void) { return kMaxQuads; }
 
 int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
@@ -454,6 +526,7 @@ int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* u
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
+    a.sync = nullptr;
     a.dbg = nullptr;
 #ifdef SGP_ABLATION
     a.dbg = pipe_dbg_buffer();

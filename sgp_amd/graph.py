@@ -178,26 +178,33 @@ class ShiftOperator:
         if plan is not None and halo is not None and \
                 halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 31:
             plan = None                      # tiled kernels use 32-bit row offsets
-        if force in ("tiled", "mfma", "pipe") and plan is None:
+        if force in ("tiled", "mfma", "pipe", "res") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
         if force == "mfma" and (plan is None or plan.gw is None):
             raise NotImplementedError("no row-group stream for this plan")
         # matrix-core row groups pay off when 4-row groups share most columns (k-NN graphs)
         use_mfma = plan is not None and plan.gw is not None and \
-            (force in ("mfma", "pipe") or (force is None and plan.group_fill >= 0.5 and
+            (force in ("mfma", "pipe", "res") or (force is None and plan.group_fill >= 0.5 and
                                  plan.max_tile_quads <= hip.load().sgp_spmm_mfma_max_quads()))
         use_pipe = use_mfma and plan.pipe is not None and force in (None, "pipe") and \
             plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
         if force == "pipe" and not use_pipe:
             raise NotImplementedError("no two-phase stream for this plan")
-        self.last_kernel = "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
+        use_res = use_mfma and plan.pipe is not None and force == "res" and \
+            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_res_max_quads() and \
+            plan.pipe["max_union"] <= hip.load().sgp_spmm_res_max_union()
+        if force == "res" and not use_res:
+            raise NotImplementedError("no two-phase stream for this plan")
+        self.last_kernel = "spmm_res" if use_res else "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
             "spmm_tiled" if plan is not None else "spmm_csr_rows")
         if plan is not None and plan.reordered and not use_mfma:
             if force == "tiled":
                 raise NotImplementedError("a reordered plan serves the row-group kernels only")
             plan = None                       # generic CSR kernel
             self.last_kernel = "spmm_csr_rows"
-        if use_pipe:
+        if use_res:
+            hip.spmm_res(plan, x, y, halo, self.num_nodes)
+        elif use_pipe:
             hip.spmm_pipe(plan, x, y, halo, self.num_nodes)
         elif use_mfma:
             hip.spmm_mfma(plan, x, y, halo, self.num_nodes)
@@ -610,6 +617,7 @@ def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=Non
     return dict(usplit=usplit.astype(np.int32), uptr=uptr2.astype(np.int32), ucol=ucol2,
                 gptr=gptr.astype(np.int32), gsup=gsup.astype(np.int32), gidx=gidx, gw=gw, fill=fill,
                 max_tile_quads=max_tile_quads, max_union=int(upad.max(initial=0)),
+                max_range_steps=int(gsup.max(initial=0)),
                 phase_cost=phase_cost, rowmap=rowmap)
 
 
@@ -733,6 +741,7 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                              max_union=ps["max_union"],
                              gidx=torch.from_numpy(ps["gidx"]), gw=torch.from_numpy(ps["gw"]),
                              rowmap=torch.from_numpy(ps["rowmap"]), fill=ps["fill"],
-                             max_tile_quads=ps["max_tile_quads"])
+                             max_tile_quads=ps["max_tile_quads"],
+                             max_range_steps=ps["max_range_steps"])
         return plan
     return None

@@ -49,6 +49,16 @@ SIGNATURES = {
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_spmm_pipe_max_union": (c_i32, []),
     "sgp_spmm_pipe_max_quads": (c_i32, []),
+    "sgp_spmm_pipe_tune": (ctypes.c_int, [c_i32, c_i32]),
+    "sgp_spmm_res_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                        c_i32, c_i32, c_i32,
+                                        c_p, c_i64, c_i64,
+                                        c_p, c_i64, c_i64, c_i32,
+                                        c_p, c_i64, c_i64,
+                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_res_max_union": (c_i32, []),
+    "sgp_spmm_res_max_quads": (c_i32, []),
+    "sgp_spmm_res_tune": (ctypes.c_int, [c_i32]),
     "sgp_spmm_mfma_max_union": (c_i32, []),
     "sgp_spmm_mfma_max_quads": (c_i32, []),
     "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
@@ -239,6 +249,27 @@ def spmm_pipe(plan, x, y, halo=None, n_own=None):
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_pipe_f32")
+
+
+def spmm_res(plan, x, y, halo=None, n_own=None):
+    """Register-resident two-phase row-group product (same plan and results as spmm_pipe)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
+    ps = plan.pipe
+    _check(lib.sgp_spmm_res_f32(
+        ps["uptr"].data_ptr(), ps["ucol"].data_ptr(), ps["usplit"].data_ptr(),
+        ps["gptr"].data_ptr(), ps["gsup"].data_ptr(), ps["gidx"].data_ptr(), ps["gw"].data_ptr(),
+        ps["rowmap"].data_ptr(),
+        plan.n_tiles, ps["max_union"], ps["max_tile_quads"],
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
+        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
+        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_res_f32")
 
 
 def tiled_limits(feat):

@@ -10,7 +10,10 @@ K = 4  ->  D_out = 320, 131 GB of output, 157 GB resident.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the SAME graph is node-partitioned across the ranks (strong scaling): reservoir
-local, one all_to_all of halo rows per hop over RCCL.  Rank 0 prints ONE JSON line.
+local, one all_to_all of halo rows per hop over RCCL.  Rank 0 prints ONE JSON line.  Started
+without a launcher (WORLD_SIZE unset), ``--gpus N`` re-executes itself under
+``torch.distributed.run`` with N ranks on 127.0.0.1; when the box shows fewer than N GPUs the
+ranks share them over gloo (functional check only -- the record says so in ``config.backend``).
 """
 import argparse
 import json
@@ -45,10 +48,20 @@ WORKLOADS = {
                t_chunk=256),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
-# Fabric-side bytes of one hop launch from rocprofv3 PMC passes of this very command
-# (profiles/r1/bench_target_summary.txt): WRITE_SIZE 2.56e7 KB + 2 x FETCH_SIZE 3.60e7 KB -- on
-# gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads (MI355X_MICROARCH.md, HBM).
-PROFILED_TRAFFIC = {"target": 2.56e7 * 1024 + 2 * 3.60e7 * 1024}
+
+
+def profiled_traffic(workload, kernel):
+    """Fabric-side bytes of one hop launch, from rocprofv3 PMC passes of this very command
+    (separate ``--pmc`` runs, MI355X_MICROARCH.md HBM section: WRITE_SIZE + 2 x FETCH_SIZE on
+    gfx950).  Counters cannot be read from inside the process, so the figure comes from
+    profiles/traffic.json, keyed by (workload, kernel): it is None for any pair that has not been
+    profiled -- a kernel change invalidates it instead of leaving a stale number behind."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f).get(f"{workload}:{kernel}")
+        return (e["bytes_per_launch"], e["source"]) if e else (None, None)
+    except (OSError, ValueError, KeyError):
+        return None, None
 
 
 def build_graph(w):
@@ -64,33 +77,75 @@ def hop_bytes(n, t, d, nnz):
     return 2 * n * t * d * 4 + nnz * 8 + (n + 1) * 4
 
 
-def cpu_baseline(w, seconds_budget=10.0):
-    """The CPU oracle (same op sequence as the reference) timed on this box's host cores on a
-    bounded sample of the workload: same F/R/K/graph family, fewer nodes and steps.  The number
-    of steps is calibrated so that the whole leg stays within ~seconds_budget."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(w, ei, ew, seconds_budget=24.0):
+    """The CPU oracle (same op sequence as the reference) timed on this box's host cores
+    (SURVEY.md 8d): the workload's own graph at full N, for as many time steps as fit the budget,
+    best of 3, once with every host thread (``os.cpu_count()``) and once with 32 (the
+    reference's published runs used a 32-process EPYC); the better one is ``value``."""
     from oracle import sgp_oracle as O
-    threads = min(os.cpu_count() or 1, 32)       # more threads only add dispatch overhead here
-    torch.set_num_threads(threads)
-    n = min(w["N"], 20000)
-    ei, ew = build_graph(dict(w, N=n))
+    n = w["N"]
     torch.manual_seed(42)
     layers = O.init_reservoir(w["F"], w["R"], num_layers=w["L"], leaking_rate=0.9,
                               spectral_radius=0.9, density=0.7)
     ops = O.shift_operators_csr(ei, ew, n, bidirectional=w["bidir"])   # graph prep: not timed
+    all_threads = os.cpu_count() or 1
+    settings = sorted({all_threads, min(all_threads, 32)}, reverse=True)
 
     def run(t):
-        x = torch.randn(t, n, w["F"])
+        x = torch.randn(t, n, w["F"], generator=torch.Generator().manual_seed(0))
         t0 = time.time()
         O.encoder_forward_prebuilt(x, ops, layers, w["K"], global_attr=w["glob"])
         return time.time() - t0
 
-    run(1)                                        # warm-up (thread pool, operator build)
-    probe = run(2) / 2                            # seconds per step
-    t = int(max(2, min(w["T"], 32, seconds_budget / 3 / max(probe, 1e-6))))
-    best = min(run(t), run(t))
-    return {"value": n * t / best, "unit": "node-steps/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/sgp_oracle.py encoder on N={n} nodes x T={t} steps of the same "
-                      f"workload (F={w['F']}, R={w['R']}, K={w['K']}, {w['graph']}), best of 2"}
+    results = {}
+    for threads in settings:
+        torch.set_num_threads(threads)
+        run(1)                                    # warm-up (thread pool)
+        probe = run(2) / 2                        # seconds per step
+        per_run = seconds_budget / len(settings) / 3.5
+        t = int(max(2, min(w["T"], per_run / max(probe, 1e-6))))
+        best = min(run(t) for _ in range(3))
+        results[threads] = (n * t / best, t)
+    threads = max(results, key=lambda k: results[k][0])
+    value, t = results[threads]
+    return {"value": value, "unit": "node-steps/s", "cores": threads, "kind": "port",
+            "cpu": cpu_model(), "host_threads": all_threads,
+            "by_threads": {str(k): v[0] for k, v in results.items()},
+            "sample": f"oracle/sgp_oracle.py encoder on the workload's own graph (N={n}, "
+                      f"F={w['F']}, R={w['R']}x{w['L']}, K={w['K']}, {w['graph']}) for T={t} of "
+                      f"{w['T']} steps, best of 3 per thread setting"}
+
+
+def relaunch(args):
+    """``python bench.py --gpus N`` without a launcher: run N ranks of this file under
+    torch.distributed.run on 127.0.0.1 and pass their one JSON line through."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        env.setdefault("SGP_BENCH_BACKEND", "gloo")     # ranks share GPUs: functional run only
+        print(f"bench.py: {n_dev} GPU(s) visible for --gpus {args.gpus}: ranks share devices over "
+              f"gloo (functional check, not a scaling measurement)", file=sys.stderr)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def main():
@@ -102,6 +157,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        hip.require_gpu()
+        relaunch(args)
+
     # stdout carries exactly ONE JSON line: everything else that ends up on file descriptor 1
     # (RCCL prints a version banner there from C, flushed at exit) is sent to stderr
     json_fd = os.dup(1)
@@ -111,9 +170,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus and "SGP_BENCH_BACKEND" not in os.environ:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with "
-                         f"--nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     hip.require_gpu()
     # SGP_BENCH_BACKEND=gloo lets several ranks share one GPU (functional check of the
     # partitioned path on a 1-GPU box); the measured configuration is nccl = RCCL, one GPU each.
@@ -146,13 +204,15 @@ def main():
         lo, hi = bounds[rank], bounds[rank + 1]
         local_ops = [b.op for b in spatial.blocks]
     else:
-        spatial, lo, hi = None, 0, N
+        spatial, bounds, lo, hi = None, [0, N], 0, N
         local_ops = ops
     n_own = hi - lo
     dump = os.environ.get("SGP_BENCH_DUMP")                # tests: same input on every layout
+    order = getattr(spatial, "node_order", None)           # rank r owns order[lo:hi] (None: lo..hi)
     if dump:
         g = torch.Generator(device=dev).manual_seed(1234)
-        x = torch.randn(T, N, F, device=dev, generator=g)[:, lo:hi].contiguous()
+        x = torch.randn(T, N, F, device=dev, generator=g)
+        x = (x[:, lo:hi] if order is None else x[:, order[lo:hi].to(dev)]).contiguous()
     else:
         g = torch.Generator(device=dev).manual_seed(1234 + rank)
         x = torch.randn(T, n_own, F, device=dev, generator=g)   # synthetic, resident in HBM
@@ -166,6 +226,7 @@ def main():
         o.device_csr(dev)
 
     hop_ms = []
+    timeline = []                    # partitioned path: ("comm" | "hop", start, end) events
 
     def step(timed):
         if state is not None:
@@ -192,6 +253,7 @@ def main():
                     p = enc.sgp_encoder.num_blocks() - 1
                     hip.node_mean_bcast(oc[:, :, :d_h], oc[:, :, p * d_h:(p + 1) * d_h])
             else:
+                spatial.timeline = timeline if timed else None
                 spatial.encode_into(oc, d_h)
 
     def barrier():
@@ -215,6 +277,8 @@ def main():
 
     if dump:
         torch.save(out.cpu(), os.path.join(dump, f"out_w{world}_r{rank}.pt"))
+        if order is not None and rank == 0:
+            torch.save(dict(order=order, bounds=bounds), os.path.join(dump, f"order_w{world}.pt"))
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = N * T * args.steps / elapsed
@@ -229,19 +293,47 @@ def main():
                                    f"{', bidirectional' if w['bidir'] else ''}"
                                    f"{', global_attr' if w['glob'] else ''}",
                        "nnz": nnz, "d_out": enc.output_size, "t_chunk": tc,
-                       "partition": f"{world} contiguous node block(s)"},
+                       "partition": f"{world} contiguous node block(s), equal nnz"
+                                    f"{', locality-reordered numbering' if order is not None else ''}",
+                       "backend": backend if (world > 1 or force_dist) else "none",
+                       "gpus_visible": torch.cuda.device_count()},
         }
         if hop_ms:
             per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
             bts = hop_bytes(N, tc, d_h, nnz)              # one launch covers one time chunk
             achieved = bts / (per_launch * 1e-3) / 1e9
+            kernel = getattr(ops[0], "last_kernel", "?")
+            traffic, source = profiled_traffic(args.workload, kernel)
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                               "traffic": PROFILED_TRAFFIC.get(args.workload),
-                               "kernel": getattr(ops[0], "last_kernel", "?"),
+                               "traffic": traffic, "traffic_source": source,
+                               "kernel": kernel,
                                "ms_per_launch": per_launch, "algorithmic_bytes": bts}
+        elif timeline:
+            # rank 0's GPU: a hop of the local block = its launches over the time chunks; the
+            # exchange of a hop = gather + all_to_all on the communication stream
+            n_hops = args.steps * (T // tc if T % tc == 0 else T // tc + 1) * K * len(local_ops)
+            hop_t = sum(a.elapsed_time(b) for kind, a, b in timeline if kind == "hop") / n_hops
+            comm_t = sum(a.elapsed_time(b) for kind, a, b in timeline if kind == "comm") / n_hops
+            blk = spatial.blocks[0]
+            nnz_local = blk.op.nnz()
+            bts = (2 * n_own + blk.n_halo) * tc * d_h * 4 + nnz_local * 8 + (n_own + 1) * 4
+            achieved = bts / (hop_t * 1e-3) / 1e9
+            rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                               "kernel": getattr(blk.op, "last_kernel", "?"),
+                               "ms_per_launch": hop_t / max(1, min(spatial.n_chunks, tc)),
+                               "algorithmic_bytes": bts,
+                               "scope": "rank 0's local block, per GPU peak"}
+            rec["multi_gpu"] = {"compute_ms_per_hop": hop_t, "comm_ms_per_hop": comm_t,
+                                "halo_rows_in": blk.n_halo, "rows_out": int(sum(blk.send_counts)),
+                                "halo_bytes_in_per_hop": blk.n_halo * tc * d_h * 4,
+                                "bytes_out_per_hop": int(sum(blk.send_counts)) * tc * d_h * 4,
+                                "owned_rows": n_own, "time_chunks_per_hop": min(spatial.n_chunks, tc),
+                                "note": "comm (row packing + all_to_all on its own stream) runs "
+                                        "under the SpMM of the previous time chunk"}
         if not args.no_cpu_baseline and world == 1:
-            rec["cpu_baseline"] = cpu_baseline(w)
+            rec["cpu_baseline"] = cpu_baseline(w, ei, ew)
         os.write(json_fd, (json.dumps(rec) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -174,6 +174,14 @@ class ShiftOperator:
         from . import hip
         if (halo is None) != (self.num_cols == self.num_nodes):
             raise ValueError("halo rows are required exactly when num_cols > num_nodes")
+        if x.dim() != 3 or y.dim() != 3 or y.shape[0] != x.shape[0] or y.shape[2] != x.shape[2]:
+            raise ValueError("propagate expects [B, N, F] operands of equal batch and feature size")
+        n_src = x.shape[1] + (0 if halo is None else halo.shape[1])
+        if n_src != self.num_cols or y.shape[1] != self.num_nodes:
+            raise ValueError(f"operand shapes do not match the operator: {n_src} source rows for "
+                             f"{self.num_cols} columns, {y.shape[1]} result rows for {self.num_nodes}")
+        if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
+            raise ValueError("halo batch / feature size differs from x")
         plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device)
         if plan is not None and halo is not None and \
                 halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 31:
@@ -186,14 +194,15 @@ class ShiftOperator:
         use_mfma = plan is not None and plan.gw is not None and \
             (force in ("mfma", "pipe", "res") or (force is None and plan.group_fill >= 0.5 and
                                  plan.max_tile_quads <= hip.load().sgp_spmm_mfma_max_quads()))
-        use_pipe = use_mfma and plan.pipe is not None and force in (None, "pipe") and \
-            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
-        if force == "pipe" and not use_pipe:
-            raise NotImplementedError("no two-phase stream for this plan")
-        use_res = use_mfma and plan.pipe is not None and force == "res" and \
+        # register-resident form first (bit-identical to spmm_pipe, faster), then spmm_pipe
+        use_res = use_mfma and plan.pipe is not None and force in (None, "res") and \
             plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_res_max_quads() and \
             plan.pipe["max_union"] <= hip.load().sgp_spmm_res_max_union()
         if force == "res" and not use_res:
+            raise NotImplementedError("no two-phase stream for this plan")
+        use_pipe = use_mfma and not use_res and plan.pipe is not None and force in (None, "pipe") and \
+            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
+        if force == "pipe" and not use_pipe:
             raise NotImplementedError("no two-phase stream for this plan")
         self.last_kernel = "spmm_res" if use_res else "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
             "spmm_tiled" if plan is not None else "spmm_csr_rows")
@@ -249,13 +258,15 @@ class ShiftOperator:
             x3 = x3.float()
         if x3.stride(2) != 1:
             x3 = x3.contiguous()
+        if x3.shape[1] != self.num_cols:
+            raise ValueError(f"operand has {x3.shape[1]} rows, the operator {self.num_cols} columns")
         on_cpu = not x3.is_cuda
         if on_cpu:
             from . import hip
             hip.require_gpu()
             x3 = x3.cuda()
-        y = torch.empty_like(x3, memory_format=torch.contiguous_format)
-        self.propagate(x3, y)
+        y = torch.empty(x3.shape[0], self.num_nodes, x3.shape[2], dtype=torch.float32, device=x3.device)
+        self.propagate_rect(x3, y)
         if on_cpu:
             y = y.cpu()
         return y.reshape(*lead, self.num_nodes, x.shape[-1])

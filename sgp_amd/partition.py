@@ -37,6 +37,30 @@ def partition_bounds(n_nodes, world_size, rowptr=None):
     return [0] + [int(c) for c in cuts] + [int(n_nodes)]
 
 
+def permute_operator(op: ShiftOperator, order) -> ShiftOperator:
+    """The square operator with nodes renumbered so that new id k is old id ``order[k]``
+    (P A P^T): row k of the result is row ``order[k]`` of ``op`` with its columns relabelled."""
+    order = torch.as_tensor(order, dtype=torch.long)
+    n = op.num_nodes
+    pos = torch.empty(n, dtype=torch.long)
+    pos[order] = torch.arange(n)
+    rp = op.rowptr.long()
+    counts = (rp[1:] - rp[:-1])[order]
+    new_rp = torch.zeros(n + 1, dtype=torch.long)
+    new_rp[1:] = torch.cumsum(counts, 0)
+    take = torch.repeat_interleave(rp[order] - new_rp[:-1], counts) + torch.arange(int(new_rp[-1]))
+    col, val = pos[op.col.long()[take]], op.val[take]
+    # columns sorted inside every row (the CSR kernels and the tile planner expect it)
+    key = torch.repeat_interleave(torch.arange(n), counts) * n + col
+    srt = torch.argsort(key)
+    return ShiftOperator(new_rp, col[srt], val[srt], n)
+
+
+def halo_rows(op: ShiftOperator, bounds, rank):
+    """Number of distinct columns outside ``rank``'s row block that its rows reference."""
+    return int(_halo_of(op, bounds[rank], bounds[rank + 1])[0].numel())
+
+
 @dataclass
 class LocalBlock:
     """Rows ``[lo, hi)`` of a global operator, columns renumbered ``[owned | halo]``."""
@@ -173,6 +197,10 @@ class PartitionedSpatial:
         self._dist = self.world_size > 1 or (force_collectives and dist.is_initialized())
         self._xchg = {}
         self._comm_stream = None
+        # bench.py sets this to a list: (kind, start event, end event) per exchange ("comm", on the
+        # communication stream) and per SpMM launch ("hop", on the compute stream)
+        self.timeline = None
+        self.node_order = None                     # set by make_partitioned_spatial
 
     def num_blocks(self):
         return 1 + len(self.blocks) * self.k + (1 if self.global_attr else 0)
@@ -190,8 +218,18 @@ class PartitionedSpatial:
                 s = 1 + d * self.k + h
                 dst = out[:, :, s * feat:(s + 1) * feat]
                 # every rank enters the collective, even one whose block has no halo
+                timed = self.timeline is not None and out.is_cuda
+                if timed:
+                    c0, c1, h1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                    c0.record()
                 halo = self._exchange(d, 0)(src) if self._dist else None
+                if timed:
+                    c1.record()
                 self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
+                if timed:
+                    h1.record()
+                    self.timeline.append(("comm", c0, c1))
+                    self.timeline.append(("hop", c1, h1))
                 src = dst
 
     def _hops_pipelined(self, out, feat):
@@ -214,16 +252,29 @@ class PartitionedSpatial:
                     t0, t1 = cuts[j], cuts[j + 1]
                     src = out[t0:t1, :, s_src * feat:(s_src + 1) * feat]
                     dst = out[t0:t1, :, s_dst * feat:(s_dst + 1) * feat]
+                    timed = self.timeline is not None
                     with torch.cuda.stream(comm):
                         comm.wait_event(ready[j])
+                        if timed:
+                            c0 = torch.cuda.Event(enable_timing=True)
+                            c0.record(comm)
                         halo = self._exchange(d, j)(src)
-                        got = torch.cuda.Event()
+                        got = torch.cuda.Event(enable_timing=timed)
                         got.record(comm)
+                    # the receive buffer was allocated on the communication stream and is read on
+                    # the compute stream
+                    halo.record_stream(main)
                     main.wait_event(got)
+                    if timed:
+                        h0 = torch.cuda.Event(enable_timing=True)
+                        h0.record(main)
                     self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
-                    ev = torch.cuda.Event()
+                    ev = torch.cuda.Event(enable_timing=timed)
                     ev.record(main)
                     done.append(ev)
+                    if timed:
+                        self.timeline.append(("comm", c0, got))
+                        self.timeline.append(("hop", h0, ev))
                 ready = done
         # the communication stream's buffers are reused by the next call: let it catch up
         comm.wait_stream(main)
@@ -249,13 +300,41 @@ class PartitionedSpatial:
 
 def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
                              rank=None, world_size=None, group=None, ops=HipOps,
-                             balance="rows", n_chunks=4, force_collectives=False):
-    """Split the forward (and backward) global operators for this rank."""
+                             balance="nnz", n_chunks=4, force_collectives=False, locality="auto"):
+    """Split the forward (and backward) global operators for this rank.
+
+    Returns ``(spatial, bounds)``; ``spatial.node_order`` is None when rank r owns the global
+    nodes ``bounds[r] .. bounds[r+1]``, else an int64 tensor and rank r owns
+    ``node_order[bounds[r]:bounds[r+1]]`` (in that order: row i of the rank's tensors is global
+    node ``node_order[bounds[r] + i]``).  ``locality``: "auto" renumbers the nodes by
+    ``graph.locality_order`` when a contiguous cut of the given numbering would make a rank fetch
+    more than half as many halo rows as it owns (a k-NN graph of stations in file order:
+    near-full exchange) and the renumbering fetches at least 30 % fewer; "never" keeps the
+    numbering; "always" renumbers.
+    ``balance``: "nnz" cuts equal edge counts (equal SpMM work), "rows" equal row counts."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
     n = ops_global[0].num_nodes
-    bounds = partition_bounds(n, world_size,
-                              ops_global[0].rowptr.numpy() if balance == "nnz" else None)
+
+    def cut(op_list):
+        return partition_bounds(n, world_size, op_list[0].rowptr.numpy() if balance == "nnz" else None)
+
+    bounds, node_order = cut(ops_global), None
+    if world_size > 1 and locality != "never" and n >= 2 * world_size:
+        mid = world_size // 2
+        own = max(1, bounds[mid + 1] - bounds[mid])
+        plain = halo_rows(ops_global[0], bounds, mid)
+        if locality == "always" or 2 * plain > own:
+            from .graph import locality_order
+            fwd = ops_global[0]
+            order = torch.from_numpy(np.ascontiguousarray(
+                locality_order(fwd.rowptr.numpy(), fwd.col.numpy(), n))).long()
+            cand = [permute_operator(op, order) for op in ops_global]
+            cb = cut(cand)
+            if locality == "always" or 10 * halo_rows(cand[0], cb, mid) < 7 * plain:
+                ops_global, bounds, node_order = cand, cb, order
     blocks = [split_operator(op, bounds, rank) for op in ops_global]
-    return PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
-                              n_chunks=n_chunks, force_collectives=force_collectives), bounds
+    spatial = PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
+                                 n_chunks=n_chunks, force_collectives=force_collectives)
+    spatial.node_order = node_order
+    return spatial, bounds

@@ -73,7 +73,7 @@ def test_spmm_csr_strided_slots_in_place():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     buf = torch.randn(t, n, p * d, device="cuda")
     ref = buf.clone()
-    for force in ("csr", "tiled", "mfma", "pipe"):
+    for force in ("csr", "tiled", "mfma", "pipe", "res"):
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
@@ -93,7 +93,7 @@ def test_spmm_tiled_knn(n, k, feat):
     plan = op.tile_plan(feat, torch.device("cuda"))
     assert plan is not None
     x = torch.randn(5, n, feat)
-    for force in ("tiled", "mfma", "pipe"):
+    for force in ("tiled", "mfma", "pipe", "res"):
         y = torch.full((5, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -112,7 +112,7 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     op = graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n)
     assert op.tile_plan(feat, torch.device("cuda")) is not None
     x = torch.randn(t, n, feat)
-    for force in ("tiled", "mfma", "pipe"):
+    for force in ("tiled", "mfma", "pipe", "res"):
         y = torch.full((t, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -123,7 +123,7 @@ def test_spmm_traffic_graph_small_n_long_t():
     ei, ew = synthetic.sparse_traffic_graph(325, 2369, seed=2)
     op = graph.ShiftOperator.from_edges(ei, ew, 325)
     x = torch.randn(600, 325, 128)
-    for force in ("csr", "tiled", "mfma", "pipe"):
+    for force in ("csr", "tiled", "mfma", "pipe", "res"):
         y = torch.empty(600, 325, 128, device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -576,7 +576,7 @@ def test_scrambled_node_labels_take_the_fast_path():
     x = torch.randn(t, n, d)
     y = torch.full((t, n, d), float("nan"), device="cuda")
     op.propagate(x.cuda(), y)
-    assert op.last_kernel == "spmm_pipe" and op.tile_plan(d, torch.device("cuda")).reordered
+    assert op.last_kernel == "spmm_res" and op.tile_plan(d, torch.device("cuda")).reordered
     close(y, dense_ref(op, x))
     y2 = torch.empty_like(y)
     op.propagate(x.cuda(), y2, force="csr")
@@ -599,7 +599,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("pipe", "mfma", "tiled", "csr"):
+    for force in ("res", "pipe", "mfma", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity
@@ -627,7 +627,7 @@ def test_properties_on_the_target_graph():
     assert plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc, yr = (torch.empty_like(x1) for _ in range(4))
-    op.propagate(x1, ya); assert op.last_kernel == "spmm_pipe"
+    op.propagate(x1, ya); assert op.last_kernel == "spmm_res"
     op.propagate(x2, yb)
     op.propagate(2 * x1 - 3 * x2, yc)
     close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)
@@ -662,7 +662,7 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
         assert blk.n_halo > 0
         xo = x[:, blk.lo:blk.hi].cuda().contiguous()
         recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()      # [rows, T, D]
-        for force in ("csr", "tiled", "mfma", "pipe"):
+        for force in ("csr", "tiled", "mfma", "pipe", "res"):
             y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
             blk.op.propagate(xo, y, force=force, halo=recv.permute(1, 0, 2))
             close(y, ref[:, blk.lo:blk.hi])
@@ -675,11 +675,35 @@ def test_bench_two_ranks_share_one_gpu_matches_single_rank(tmp_path):
     global mean) with 2 ranks on this one GPU over gloo == the single-rank result."""
     import subprocess, sys, json
     from conftest import ROOT
-    env = dict(os.environ, SGP_BENCH_BACKEND="gloo", SGP_BENCH_DUMP=str(tmp_path))
+    env = dict(os.environ, SGP_BENCH_DUMP=str(tmp_path))
+    env.pop("WORLD_SIZE", None)
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small",
                           "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
+    # the driver's command form: no launcher, bench.py starts its own ranks (they share this
+    # box's single GPU over gloo when fewer than 2 devices are visible)
+    two = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                          "--workload", "small", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-2000:]
+    lines = [l for l in two.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["value"] > 0
+    assert rec["roofline"]["frac"] > 0 and rec["roofline"]["bound"] == "hbm"
+    mg = rec["multi_gpu"]
+    assert mg["compute_ms_per_hop"] > 0 and mg["comm_ms_per_hop"] > 0 and mg["halo_rows_in"] > 0
+    full = torch.load(tmp_path / "out_w1_r0.pt")
+    parts = [torch.load(tmp_path / f"out_w2_r{r}.pt") for r in range(2)]
+    close(torch.cat(parts, 1), full, rtol=1e-6, atol=1e-6)
+
+
+def test_bench_under_an_external_launcher(tmp_path):
+    """The launcher form of the contract (torch.distributed.run starts the ranks) still works."""
+    import subprocess, sys, json
+    from conftest import ROOT
+    env = dict(os.environ, SGP_BENCH_BACKEND="gloo")
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                           "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
                           str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"),
@@ -687,10 +711,7 @@ def test_bench_two_ranks_share_one_gpu_matches_single_rank(tmp_path):
                          env=env, capture_output=True, text=True, timeout=900)
     assert two.returncode == 0, two.stderr[-2000:]
     rec = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 2 and rec["value"] > 0
-    full = torch.load(tmp_path / "out_w1_r0.pt")
-    parts = [torch.load(tmp_path / f"out_w2_r{r}.pt") for r in range(2)]
-    close(torch.cat(parts, 1), full, rtol=1e-6, atol=1e-6)
+    assert rec["n_gpus"] == 2 and rec["config"]["backend"] == "gloo"
 
 
 def test_streamed_encoding_equals_single_pass():

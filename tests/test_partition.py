@@ -77,22 +77,30 @@ def _worker(rank, world, port, cfg, ret):
         torch.manual_seed(0)
         n, t, d, k = cfg["n"], 5, 8, cfg["k"]
         ei, ew, _ = synthetic.knn_graph(n, 7, seed=4)
+        if cfg.get("scramble"):                       # node numbering without locality
+            ei = torch.randperm(n, generator=torch.Generator().manual_seed(3))[ei]
         ops = spatial_operators(ei, ew, n, bidirectional=cfg["bidir"])
         x = torch.randn(t, n, d)
-        enc, bounds = partition.make_partitioned_spatial(ops, k, cfg["glob"], ops=TorchOps)
+        enc, bounds = partition.make_partitioned_spatial(ops, k, cfg["glob"], ops=TorchOps,
+                                                         balance=cfg.get("balance", "nnz"))
         lo, hi = bounds[rank], bounds[rank + 1]
+        assert (enc.node_order is not None) == bool(cfg.get("scramble"))
+        rows = torch.arange(lo, hi) if enc.node_order is None else enc.node_order[lo:hi]
         out = torch.zeros(t, hi - lo, enc.num_blocks() * d)
-        out[:, :, :d] = x[:, lo:hi]
+        out[:, :, :d] = x[:, rows]
         enc.encode_into(out, d)
         ref = O.spatial_encoder_forward(x, ei, ew, k, cfg["bidir"], False, cfg["glob"])
-        ok = torch.allclose(out, ref[:, lo:hi], rtol=1e-5, atol=1e-5)
-        ret[rank] = (bool(ok), float((out - ref[:, lo:hi]).abs().max()))
+        ok = torch.allclose(out, ref[:, rows], rtol=1e-5, atol=1e-5)
+        if cfg.get("scramble"):                       # the renumbering keeps the exchange compact
+            ok = ok and enc.blocks[0].n_halo < (hi - lo)
+        ret[rank] = (bool(ok), float((out - ref[:, rows]).abs().max()))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("cfg", [dict(n=150, k=3, bidir=True, glob=True),
-                                 dict(n=97, k=2, bidir=False, glob=False)])
+                                 dict(n=97, k=2, bidir=False, glob=False, balance="rows"),
+                                 dict(n=900, k=2, bidir=True, glob=True, scramble=True)])
 def test_two_rank_gloo_matches_single_process(cfg):
     world = 2
     port = 29500 + (os.getpid() % 2000)
@@ -102,3 +110,34 @@ def test_two_rank_gloo_matches_single_process(cfg):
     assert len(ret) == world
     for r in range(world):
         assert ret[r][0], f"rank {r}: max err {ret[r][1]}"
+
+
+def test_permute_operator_is_a_relabelling():
+    ei, ew, _ = synthetic.knn_graph(120, 6, seed=8)
+    op = graph.ShiftOperator.from_edges(ei, ew, 120)
+    order = torch.randperm(120, generator=torch.Generator().manual_seed(1))
+    p = partition.permute_operator(op, order)
+    assert torch.equal(p.to_dense(), op.to_dense()[order][:, order])
+    rp = p.rowptr.long()
+    for r in range(120):                               # columns sorted inside every row
+        c = p.col[rp[r]:rp[r + 1]]
+        assert torch.all(c[1:] > c[:-1])
+
+
+def test_locality_renumbering_shrinks_the_halo_of_a_scrambled_graph():
+    n, world = 4000, 8
+    ei, ew, _ = synthetic.knn_graph(n, 12, seed=6)
+    ei = torch.randperm(n, generator=torch.Generator().manual_seed(2))[ei]
+    ops = spatial_operators(ei, ew, n)
+    plain = partition.halo_rows(ops[0], partition.partition_bounds(n, world), world // 2)
+    enc, bounds = partition.make_partitioned_spatial(ops, 2, False, rank=world // 2, world_size=world,
+                                                     ops=TorchOps)
+    assert enc.node_order is not None and sorted(enc.node_order.tolist()) == list(range(n))
+    own = bounds[world // 2 + 1] - bounds[world // 2]
+    assert plain > 4 * own                              # near-full exchange without it
+    assert enc.blocks[0].n_halo < own                   # boundary strip with it
+    # a graph whose numbering already has locality is left alone
+    ei2, ew2, _ = synthetic.knn_graph(n, 12, seed=6)
+    enc2, _ = partition.make_partitioned_spatial(spatial_operators(ei2, ew2, n), 2, False,
+                                                 rank=1, world_size=world, ops=TorchOps)
+    assert enc2.node_order is None

@@ -179,6 +179,38 @@ int32_t sgp_spmm_res_max_union(void);
 int32_t sgp_spmm_res_max_quads(void);
 int sgp_spmm_res_tune(int32_t cfg);
 
+/* Row-block form of the row-group product (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
+ * sgp_amd/rowblock.py).  A workgroup of sgp_spmm_blk_waves() = 8 waves owns a tile of up to 128
+ * rows; a wave owns FOUR 4-row groups, one per 16-lane class of v_mfma_f32_4x4x1_16b_f32, and
+ * every class walks its own column list, so a lane's accumulators hold finished sums (no fold
+ * across lanes).  Staging as in sgp_spmm_pipe_f32 (two LDS-DMA segments per step).  Arrays:
+ *   uptr[n_tiles + 1], ucol[]      staged source rows of a tile, segment A first (padded to 4 rows)
+ *   usplit[n_tiles]                rows of segment A
+ *   wptr[2 * waves * n_tiles + 1]  first super-step of (tile, wave, segment) in soff / sw
+ *                                  (multiples of 4), nsteps[] = its length (longest class)
+ *   soff[n_super][4]               LDS byte offset (staged row * 256) of class q's source row
+ *   sw[n_super / 4][64]            weights, one float per lane and 4 super-steps: lane
+ *                                  16 q + 4 b + i = row i of class q in super-step 4 p + b
+ *   rowmap[16 * waves * n_tiles]   result row of (tile, wave, class, i), -1 = none
+ * max_union = staged rows of the largest tile (<= sgp_spmm_blk_max_union()).  X / X_halo / Y as
+ * in sgp_spmm_tiled_f32.  Arithmetic: exact fp32 FMA chain per (row, feature) in the order of the
+ * class's staged rows. */
+int sgp_spmm_blk_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+                     const int32_t* wptr, const int32_t* nsteps, const int32_t* soff, const float* sw,
+                     const int32_t* rowmap,
+                     int32_t n_tiles, int32_t waves, int32_t max_union,
+                     const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                     const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                     int32_t n_own,
+                     float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                     int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                     sgp_stream_t stream);
+int32_t sgp_spmm_blk_max_union(void);
+int32_t sgp_spmm_blk_waves(void);
+/* Register split of the kernel (process-wide): 0 = 72 resident super-steps per segment and an
+ * operand ring 4 deep, 1 = 64 / 6, 2 = 56 / 8.  Results do not depend on it. */
+int sgp_spmm_blk_tune(int32_t cfg);
+
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and
  * largest padded per-row edge count. */

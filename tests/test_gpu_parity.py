@@ -119,6 +119,49 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
         assert float(y[:, ::7].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("n,k,feat,t", [(1500, 20, 64, 5), (1500, 100, 64, 5), (900, 33, 128, 3),
+                                        (3000, 50, 64, 40), (700, 20, 192, 2)])
+def test_spmm_row_block_kernel(n, k, feat, t):
+    """sgp_spmm_blk_f32 (128-row tiles, a wave walks four row groups in its four lane classes)
+    against the dense fp32 product; t = 40 spans two time chunks."""
+    torch.manual_seed(n + k)
+    ei, ew, _ = synthetic.knn_graph(n, k, seed=7)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    assert op.block_plan(feat, torch.device("cuda")) is not None
+    x = torch.randn(t, n, feat)
+    y = torch.full((t, n, feat), float("nan"), device="cuda")
+    op.propagate(x.cuda(), y, force="blk")
+    close(y, dense_ref(op, x))
+    y2 = torch.empty_like(y)
+    op.propagate(x.cuda(), y2, force="csr")
+    close(y, y2, rtol=1e-6, atol=1e-6)
+
+
+def test_spmm_row_block_ragged_rows_and_long_ranges():
+    """Empty rows, ragged degrees, and groups whose column lists exceed the register-resident
+    part of the stream (rows that mix two distant neighbourhoods -> the overflow path)."""
+    torch.manual_seed(6)
+    n, feat, t = 2048, 64, 35
+    deg = torch.randint(0, 60, (n,))
+    deg[::7] = 0
+    tgt = torch.repeat_interleave(torch.arange(n), deg)
+    src = (tgt + torch.randint(-40, 41, tgt.shape)).clamp(0, n - 1)
+    # every 5th row also references a window 150 rows away: long, poorly shared column lists
+    far = torch.arange(0, n, 5)
+    far_t = torch.repeat_interleave(far, 90)
+    far_s = (far_t + 150 + torch.randint(0, 120, far_t.shape)) % n
+    ei = torch.stack([torch.cat([src, far_s]), torch.cat([tgt, far_t])])
+    op = graph.ShiftOperator.from_edges(ei, torch.rand(ei.shape[1]) + .1, n)
+    plan = op.block_plan(feat, torch.device("cuda"))
+    assert plan is not None and plan.max_steps > 72      # exercises the overflow path
+    x = torch.randn(t, n, feat)
+    y = torch.full((t, n, feat), float("nan"), device="cuda")
+    op.propagate(x.cuda(), y, force="blk")
+    close(y, dense_ref(op, x))
+    empty = (op.rowptr[1:] == op.rowptr[:-1]).nonzero().flatten()
+    assert empty.numel() > 0 and float(y[:, empty].abs().max()) == 0.0
+
+
 def test_spmm_traffic_graph_small_n_long_t():
     ei, ew = synthetic.sparse_traffic_graph(325, 2369, seed=2)
     op = graph.ShiftOperator.from_edges(ei, ew, 325)
@@ -577,6 +620,10 @@ def test_scrambled_node_labels_take_the_fast_path():
     y = torch.full((t, n, d), float("nan"), device="cuda")
     op.propagate(x.cuda(), y)
     assert op.last_kernel == "spmm_res" and op.tile_plan(d, torch.device("cuda")).reordered
+    y3 = torch.empty_like(y)
+    op.propagate(x.cuda(), y3, force="blk")
+    assert op.block_plan(d, torch.device("cuda")).reordered
+    close(y3, dense_ref(op, x))
     close(y, dense_ref(op, x))
     y2 = torch.empty_like(y)
     op.propagate(x.cuda(), y2, force="csr")
@@ -599,7 +646,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("res", "pipe", "mfma", "tiled", "csr"):
+    for force in ("blk", "res", "pipe", "mfma", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity
@@ -628,6 +675,8 @@ def test_properties_on_the_target_graph():
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc, yr = (torch.empty_like(x1) for _ in range(4))
     op.propagate(x1, ya); assert op.last_kernel == "spmm_res"
+    op.propagate(x1, yr, force="blk")
+    close(ya, yr, rtol=1e-6, atol=1e-6)
     op.propagate(x2, yb)
     op.propagate(2 * x1 - 3 * x2, yc)
     close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)
@@ -662,7 +711,7 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
         assert blk.n_halo > 0
         xo = x[:, blk.lo:blk.hi].cuda().contiguous()
         recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()      # [rows, T, D]
-        for force in ("csr", "tiled", "mfma", "pipe", "res"):
+        for force in ("csr", "tiled", "mfma", "pipe", "res", "blk"):
             y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
             blk.op.propagate(xo, y, force=force, halo=recv.permute(1, 0, 2))
             close(y, ref[:, blk.lo:blk.hi])

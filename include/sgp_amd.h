@@ -241,6 +241,31 @@ int sgp_reservoir_f32(const float* x, int64_t x_row_stride, int64_t x_step_strid
                       int32_t T, int32_t N, int32_t F, int32_t R,
                       sgp_stream_t stream);
 
+/* All L layers of a narrow stacked reservoir in ONE launch (lib/nn/reservoir/reservoir.py:170-180:
+ * the reference steps every layer inside one time step, layer l consuming layer l-1's new state).
+ * The layers are pipelined as a wavefront over the waves of a workgroup (layer l on step t while
+ * layer l+1 is on step t-1, hand-off through LDS), layer inputs never travel through HBM.
+ *   w_ih / w_hh / b / alpha: HOST arrays of length L; w_ih[l] ([R, F] for l = 0, else [R, R]),
+ *        w_hh[l] ([R, R]), b[l] ([R]) are DEVICE pointers to the reference's parameters
+ *        (reservoir.py:42-52), alpha[l] the layer's leaking rate (reservoir.py:109-123)
+ *   out: [T, N, >= L*R] strides (out_step_stride, out_row_stride, 1); layer l fills columns
+ *        l*R .. (l+1)*R-1 of every step (the layer-major order of reservoir.py:181-183)
+ *   h_state: optional [L, N, R] contiguous, initial states in / final states out; NULL = zeros
+ *   workspace: sgp_reservoir_fused_workspace_bytes(F, R, L) bytes of device scratch, 16-byte aligned
+ * Built for F <= 64, R <= 64, 2 <= L <= 16 with all layers' weights in LDS
+ * (sgp_reservoir_fused_supported); other shapes: SGP_EUNSUP, run sgp_reservoir_f32 per layer.
+ * Same exact-fp32 MFMA products as sgp_reservoir_f32; deeper layers sum their input part in the
+ * k order of the recurrent part, so results agree to rounding, not bitwise. */
+int64_t sgp_reservoir_fused_workspace_bytes(int32_t F, int32_t R, int32_t L);
+int32_t sgp_reservoir_fused_supported(int32_t F, int32_t R, int32_t L);
+int sgp_reservoir_fused_f32(const float* x, int64_t x_row_stride, int64_t x_step_stride,
+                            const float* const* w_ih, const float* const* w_hh, const float* const* b,
+                            const double* alpha, int32_t act,
+                            float* out, int64_t out_row_stride, int64_t out_step_stride,
+                            float* h_state, void* workspace,
+                            int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
+                            sgp_stream_t stream);
+
 /* --------------------------------------------------------------- DynGESN ---
  * The graph echo-state baseline (lib/nn/reservoir/graph_reservoir.py:85-93, stepped by
  * tsl/nn/blocks/encoders/gcrnn.py:67-93):

@@ -1,0 +1,416 @@
+// Fused multi-layer leaky echo-state reservoir: ALL layers of a narrow stacked reservoir in one
+// launch (reference: lib/nn/reservoir/reservoir.py:170-180 -- the Python loop steps every layer
+// inside one time step, layer l consuming layer l-1's NEW state of the same step).
+//
+//   h_l[t] = (1 - a_l) h_l[t-1] + a_l act( W_ih,l x_l[t] + b_l + W_hh,l h_l[t-1] ),
+//   x_0[t] = x[t],  x_l[t] = h_{l-1}[t]
+//
+// (l, t) depends on (l-1, t) and (l, t-1): a wavefront.  A workgroup owns NTW node tiles of 16
+// nodes; wave (tile slot ts, layer l) keeps h_l of its tile in registers for all T steps and, in
+// iteration i, computes time step t = i - l: layer l works on step t while layer l+1 works on
+// step t-1.  The hand-off h_l[t] -> x_{l+1}[t] goes through a double-buffered LDS slab in the
+// accumulator layout of v_mfma_f32_16x16x4_f32 (lane = node + 16 q, register r <-> feature
+// 16 jt + 4 q + r), which IS the B-operand layout of the consumer (reservoir_impl.h), so the
+// producer stores its registers as they are; one s_barrier per iteration.  The layer-by-layer
+// form (sgp_reservoir_f32 once per layer) runs L serial chains of T steps and re-reads every
+// layer's slot from HBM; here the chain is T + L - 1 iterations and layer inputs never leave the
+// CU.  PV-US shape (N = 5016, T = 8868, R = 16 x 8 layers): one chain of 8875 instead of 8 x 8868.
+//
+// The recurrent MFMAs of a step are issued before the input MFMAs, so the LDS read of the
+// producer's state lands under them.  Nothing in an iteration waits for HBM: layer 0 prefetches
+// its input rows PF steps ahead, results are stored at the top of the NEXT step, and the barrier
+// is a bare `s_waitcnt lgkmcnt(0); s_barrier` (hipcc's __syncthreads would drain vmcnt too).
+#include "reservoir_impl.h"
+
+namespace {
+using namespace sgp_res;
+
+constexpr int kMaxLayers = 16;
+template <int I> struct IntK { static constexpr int value = I; };
+
+struct StackArgs {
+    const float* x; long long xrs, xss;
+    const float* wp;                 // packed weights of all layers (global workspace)
+    float* out; long long ors, oss;
+    float* h_state;                  // [L, N, R] or null
+    float alpha[kMaxLayers], oma[kMaxLayers];
+    int act, T, N, F, R, L, ntw, n_tiles;
+};
+
+// per-layer block of the packed weights (floats): bias [JT*16] | W_in | W_hh [JT][JT][64][4];
+// W_in of layer 0 is the Wx fragment order of reservoir_impl.h ([JT][NKX][64] or
+// [JT][NKX/4][64][4]), W_in of deeper layers the W_hh order applied to W_ih ([R, R]).
+__host__ __device__ constexpr int win_floats(int JT, int NKX) {
+    return JT * NKX * 64 > JT * JT * 256 ? JT * NKX * 64 : JT * JT * 256;
+}
+__host__ __device__ constexpr int layer_floats(int JT, int NKX) {
+    return JT * 16 + win_floats(JT, NKX) + JT * JT * 256;
+}
+
+struct StackPtrs { const float* w_ih[kMaxLayers]; const float* w_hh[kMaxLayers]; const float* b[kMaxLayers]; };
+
+__global__ void pack_stack(StackPtrs ptr, float* __restrict__ out, int F, int R, int JT, int NKX, int L) {
+    const float* const* w_ih = ptr.w_ih;
+    const float* const* w_hh = ptr.w_hh;
+    const float* const* b = ptr.b;
+    const int LB = layer_floats(JT, NKX), WIN = win_floats(JT, NKX);
+    const long long total = (long long)L * LB;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int l = (int)(i / LB);
+        const int o0 = (int)(i % LB);
+        float v = 0.f;
+        if (o0 < JT * 16) {
+            v = o0 < R ? b[l][o0] : 0.f;
+        } else if (o0 < JT * 16 + WIN) {
+            const int o = o0 - JT * 16;
+            if (l == 0) {
+                if (o < JT * NKX * 64) {
+                    int ln, ks, jt;
+                    if (NKX % 4 == 0) {              // [JT][NKX/4][64][4]
+                        const int s = o & 3;
+                        ln = (o >> 2) & 63;
+                        const int k4 = (o >> 8) % (NKX / 4);
+                        jt = (o >> 8) / (NKX / 4);
+                        ks = 4 * k4 + s;
+                    } else {                         // [JT][NKX][64]
+                        ln = o & 63;
+                        ks = (o >> 6) % NKX;
+                        jt = (o >> 6) / NKX;
+                    }
+                    const int j = 16 * jt + (ln & 15);
+                    const int k = (ln >> 4) * NKX + ks;
+                    v = (j < R && k < F) ? w_ih[0][(long long)j * F + k] : 0.f;
+                }
+            } else if (o < JT * JT * 256) {
+                const int s = o & 3, ln = (o >> 2) & 63;
+                const int kb = (o >> 8) % JT, jt = (o >> 8) / JT;
+                const int j = 16 * jt + (ln & 15), k = 16 * kb + 4 * (ln >> 4) + s;
+                v = (j < R && k < R) ? w_ih[l][(long long)j * R + k] : 0.f;
+            }
+        } else {
+            const int o = o0 - JT * 16 - WIN;
+            const int s = o & 3, ln = (o >> 2) & 63;
+            const int kb = (o >> 8) % JT, jt = (o >> 8) / JT;
+            const int j = 16 * jt + (ln & 15), k = 16 * kb + 4 * (ln >> 4) + s;
+            v = (j < R && k < R) ? w_hh[l][(long long)j * R + k] : 0.f;
+        }
+        out[i] = v;
+    }
+}
+
+template <int JT, int NKX>
+__global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
+    constexpr int WIN = win_floats(JT, NKX);
+    constexpr int LB = layer_floats(JT, NKX);
+    constexpr int PF = NKX <= 4 ? 4 : 2;                 // input rows in flight (layer 0)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int L = a.L;
+    {
+        const int total4 = L * LB / 4;
+        for (int i = threadIdx.x; i < total4; i += blockDim.x)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wp)[i];
+    }
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l = wave % L, ts = wave / L;
+    const int tile = blockIdx.x * a.ntw + ts;
+    const int node = tile * 16 + n_in;
+    const bool ok = tile < a.n_tiles && node < a.N;
+    // hand-off slabs: [tile slot][layer][2][JT][64] f32x4
+    f32x4* ring = reinterpret_cast<f32x4*>(lds + L * LB) + (long long)(ts * L) * 2 * JT * 64;
+    f32x4* ring_out = ring + (long long)l * 2 * JT * 64;
+    const f32x4* ring_in = ring + (long long)(l > 0 ? l - 1 : 0) * 2 * JT * 64;
+
+    const float* bias = lds + l * LB;
+    const float* wx = bias + JT * 16;
+    const float* wh = wx + WIN;
+    const float al = a.alpha[l], om = a.oma[l];
+
+    f32x4 h[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.h_state && ok) {
+            const int j0 = 16 * jt + 4 * q;
+            const float* hp = a.h_state + ((long long)l * a.N + node) * a.R + j0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + r < a.R) hv[r] = hp[r];
+        }
+        h[jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
+                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
+    float* const out_l = a.out + (long long)node * a.ors + (long long)l * a.R;
+    auto store_h = [&](int t) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j0 = 16 * jt + 4 * q;
+            if (ok && j0 < a.R) {
+                float* op = out_l + (long long)t * a.oss + j0;
+                if (o_vec) {
+                    *reinterpret_cast<f32x4*>(op) = h[jt];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + r < a.R) op[r] = h[jt][r];
+                }
+            }
+        }
+    };
+    auto load_x = [&](int t, float (&dst)[NKX]) {
+        const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks)
+            dst[ks] = (ok && t < a.T && q * NKX + ks < a.F) ? xp[ks] : 0.f;
+    };
+    float xq[PF][NKX];                                   // xq[p] = input row of step t + p (layer 0)
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) xq[p][ks] = 0.f;
+    if (l == 0) {
+#pragma unroll
+        for (int p = 0; p < PF - 1; ++p) load_x(p, xq[p]);
+    }
+    __syncthreads();                                     // weights in LDS
+
+    const int n_iter = a.T + L - 1;
+    // one iteration; P = i mod PF is static so that layer 0's input ring needs no register moves
+    // (xq[(P + p) % PF] = row of step t + p; a move would wait for the row requested a moment ago)
+    auto iteration = [&](int i, auto P) {
+        constexpr int P0 = decltype(P)::value;
+        const int t = i - l;
+        if (t >= 0 && t < a.T) {                         // wave-uniform
+            // wide layers: keep the fragments in LDS (the compiler would hoist 128 VGPRs of
+            // weights out of the time loop); narrow ones are welcome to stay in registers
+            int wo = 0;
+            if constexpr (JT >= 4) asm volatile("" : "+v"(wo));
+            const float* bias_t = bias + wo;
+            const float* wx_t = wx + wo;
+            const float* wh_t = wh + wo;
+            if (t > 0) store_h(t - 1);                   // h still holds the state of step t-1
+            f32x4 hin[JT];
+            if (l > 0) {
+                const f32x4* src = ring_in + ((i - 1) & 1) * JT * 64;
+#pragma unroll
+                for (int kb = 0; kb < JT; ++kb) hin[kb] = src[kb * 64 + lane];
+            } else {
+                load_x(t + PF - 1, xq[(P0 + PF - 1) % PF]);
+            }
+            f32x4 acc[JT];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+            // recurrent part first: its operands are this wave's registers
+#pragma unroll
+            for (int kb = 0; kb < JT; ++kb) {
+                f32x4 wf[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+                    wf[jt] = *reinterpret_cast<const f32x4*>(wh_t + ((jt * JT + kb) * 64 + lane) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jt][s], h[kb][s], acc[jt], 0, 0, 0);
+            }
+            // input part
+            if (l > 0) {
+#pragma unroll
+                for (int kb = 0; kb < JT; ++kb) {
+                    f32x4 wf[JT];
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        wf[jt] = *reinterpret_cast<const f32x4*>(wx_t + ((jt * JT + kb) * 64 + lane) * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+#pragma unroll
+                        for (int jt = 0; jt < JT; ++jt)
+                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jt][s], hin[kb][s], acc[jt], 0, 0, 0);
+                }
+            } else if constexpr (NKX % 4 == 0) {
+#pragma unroll
+                for (int k4 = 0; k4 < NKX / 4; ++k4)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wx_t + ((jt * (NKX / 4) + k4) * 64 + lane) * 4);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xq[P0][4 * k4 + s], acc[jt], 0, 0, 0);
+                    }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane], xq[P0][ks],
+                                                                       acc[jt], 0, 0, 0);
+            }
+            if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_f32(acc[jt][r]);
+            } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+            } else if (a.act == SGP_ACT_SELF_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss = fmaf(acc[jt][r], acc[jt][r], ss);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize(eps=1e-12)
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
+            }
+            // leak, publish for the next layer (stored to HBM at the top of the next step)
+            f32x4* dst = ring_out + (i & 1) * JT * 64;
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[jt][r] = om * h[jt][r] + al * acc[jt][r];
+                if (l + 1 < L) dst[jt * 64 + lane] = h[jt];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // layer 0 has t = i, so slot i mod PF is the row of its current step; the other layers ignore P
+    for (int i0 = 0; i0 < n_iter; i0 += PF) {
+        iteration(i0, IntK<0>{});
+        if constexpr (PF > 1) { if (i0 + 1 < n_iter) iteration(i0 + 1, IntK<1 % PF>{}); }
+        if constexpr (PF > 2) { if (i0 + 2 < n_iter) iteration(i0 + 2, IntK<2 % PF>{}); }
+        if constexpr (PF > 3) { if (i0 + 3 < n_iter) iteration(i0 + 3, IntK<3 % PF>{}); }
+    }
+    if (a.T > 0) store_h(a.T - 1);
+    if (a.h_state) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ok && j0 + r < a.R) a.h_state[((long long)l * a.N + node) * a.R + j0 + r] = h[jt][r];
+        }
+    }
+}
+
+template <int JT, int NKX>
+long long stack_lds_bytes(int L, int ntw) {
+    return ((long long)L * layer_floats(JT, NKX) + (long long)ntw * L * 2 * JT * 64 * 4) * 4;
+}
+
+template <int JT, int NKX>
+int launch_stack(StackArgs a, hipStream_t s) {
+    a.n_tiles = (a.N + 15) / 16;
+    // node tiles per workgroup: as many as 16 waves hold once there are more tiles than the chip
+    // has room for side by side; small graphs spread one tile per workgroup over the CUs
+    int ntw = 16 / a.L;
+    if (ntw < 1) ntw = 1;
+    while (ntw > 1 && (a.n_tiles + ntw - 1) / ntw < 512) ntw >>= 1;
+    while (ntw > 1 && stack_lds_bytes<JT, NKX>(a.L, ntw) > kLdsLimit) ntw >>= 1;
+    if (stack_lds_bytes<JT, NKX>(a.L, ntw) > kLdsLimit)
+        return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: %d layers of %d units exceed the LDS", a.L, a.R);
+    a.ntw = ntw;
+    auto kern = reservoir_stack<JT, NKX>;
+    const int bytes = (int)stack_lds_bytes<JT, NKX>(a.L, ntw);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return sgp::fail((int)e, "reservoir_stack: LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3((a.n_tiles + ntw - 1) / ntw), dim3(64 * a.L * ntw), (size_t)bytes, s, a);
+    return sgp::check_launch("reservoir_stack");
+}
+
+template <int JT>
+int launch_stack_nkx(const StackArgs& a, int nkx, hipStream_t s) {
+    switch (nkx) {
+        case 1: return launch_stack<JT, 1>(a, s);
+        case 2: return launch_stack<JT, 2>(a, s);
+        case 4: return launch_stack<JT, 4>(a, s);
+        case 8: return launch_stack<JT, 8>(a, s);
+        case 16: return launch_stack<JT, 16>(a, s);
+    }
+    return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: input size not supported");
+}
+
+int stack_nkx(int F) {
+    const int need = (F + 3) / 4;
+    const int opts[] = {1, 2, 4, 8, 16};
+    for (int o : opts) if (o >= need) return o;
+    return 0;
+}
+int stack_jt(int R) { return R <= 16 ? 1 : (R <= 32 ? 2 : (R <= 64 ? 4 : 0)); }
+
+}  // namespace
+
+extern "C" {
+
+int64_t sgp_reservoir_fused_workspace_bytes(int32_t F, int32_t R, int32_t L) {
+    const int jt = stack_jt(R), nkx = stack_nkx(F);
+    if (!jt || !nkx || L < 1 || L > kMaxLayers) return -1;
+    return (int64_t)L * layer_floats(jt, nkx) * 4;
+}
+
+int32_t sgp_reservoir_fused_supported(int32_t F, int32_t R, int32_t L) {
+    const int jt = stack_jt(R), nkx = stack_nkx(F);
+    if (!jt || !nkx || L < 2 || L > kMaxLayers) return 0;
+    const long long lds = ((long long)L * layer_floats(jt, nkx) + (long long)L * 2 * jt * 64 * 4) * 4;
+    return lds <= kLdsLimit ? 1 : 0;
+}
+
+int sgp_reservoir_fused_f32(const float* x, int64_t xrs, int64_t xss,
+                            const float* const* w_ih, const float* const* w_hh, const float* const* b,
+                            const double* alpha, int32_t act,
+                            float* out, int64_t ors, int64_t oss,
+                            float* h_state, void* workspace,
+                            int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
+                            sgp_stream_t stream) {
+    SGP_REQUIRE(x && w_ih && w_hh && b && alpha && out && workspace, "sgp_reservoir_fused_f32: null pointer");
+    SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0 && L >= 1, "sgp_reservoir_fused_f32: bad size");
+    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_reservoir_fused_f32: unknown activation %d", act);
+    SGP_REQUIRE(sgp::aligned16(workspace), "sgp_reservoir_fused_f32: workspace must be 16-byte aligned");
+    for (int l = 0; l < L && l < kMaxLayers; ++l)
+        SGP_REQUIRE(w_ih[l] && w_hh[l] && b[l], "sgp_reservoir_fused_f32: null weight pointer (layer %d)", l);
+    if (T == 0 || N == 0) return 0;
+    const int jt = stack_jt(R), nkx = stack_nkx(F);
+    if (!jt || !nkx || L > kMaxLayers)
+        return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: F=%d R=%d L=%d outside the fused kernel "
+                         "(F <= 64, R <= 64, L <= %d): run sgp_reservoir_f32 per layer", F, R, L, kMaxLayers);
+    hipStream_t s = (hipStream_t)stream;
+    const long long wfloats = (long long)L * layer_floats(jt, nkx);
+    StackPtrs ptr = {};
+    for (int l = 0; l < L; ++l) { ptr.w_ih[l] = w_ih[l]; ptr.w_hh[l] = w_hh[l]; ptr.b[l] = b[l]; }
+    int pg = (int)((wfloats + 255) / 256);
+    if (pg > 1024) pg = 1024;
+    hipLaunchKernelGGL(pack_stack, dim3(pg), dim3(256), 0, s, ptr, (float*)workspace, F, R, jt, nkx, L);
+    int rc = sgp::check_launch("pack_stack");
+    if (rc) return rc;
+
+    StackArgs a;
+    a.x = x; a.xrs = xrs; a.xss = xss;
+    a.wp = (const float*)workspace;
+    a.out = out; a.ors = ors; a.oss = oss;
+    a.h_state = h_state;
+    for (int l = 0; l < kMaxLayers; ++l) {
+        const double al = l < L ? alpha[l] : 0.0;
+        a.alpha[l] = (float)al;                    // scalars rounded to fp32 like torch does for
+        a.oma[l] = (float)(1.0 - al);              // `(1 - alpha) * h` (reservoir.py:80)
+    }
+    a.act = act; a.T = T; a.N = N; a.F = F; a.R = R; a.L = L; a.ntw = 1; a.n_tiles = 0;
+    switch (jt) {
+        case 1: return launch_stack_nkx<1>(a, nkx, s);
+        case 2: return launch_stack_nkx<2>(a, nkx, s);
+        case 4: return launch_stack_nkx<4>(a, nkx, s);
+    }
+    return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: unreachable");
+}
+
+}  // extern "C"

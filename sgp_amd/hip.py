@@ -80,6 +80,14 @@ SIGNATURES = {
                                          c_p, c_i64, c_i64,
                                          c_p, c_p,
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_reservoir_fused_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgp_reservoir_fused_supported": (c_i32, [c_i32, c_i32, c_i32]),
+    "sgp_reservoir_fused_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
+                                               c_p, c_p, c_p,
+                                               c_p, c_i32,
+                                               c_p, c_i64, c_i64,
+                                               c_p, c_p,
+                                               c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_gesn_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgp_gesn_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
                                     c_p, c_i64, c_i64, c_p, c_p,
@@ -311,6 +319,55 @@ def tiled_limits(feat):
 
 
 # ---------------------------------------------------------------- reservoir
+_WORKSPACES = {}
+
+
+def _workspace(device, nbytes):
+    """Device scratch for packed weights, reused per (device, stream): kernels of one stream run
+    in order and every call re-packs, so a call never reads what another left behind."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(max(nbytes // 4 + 1, 1024), dtype=torch.float32, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def reservoir_fused_supported(F, R, L):
+    """True when all L layers fit the fused multi-layer kernel (sgp_reservoir_fused_f32)."""
+    return bool(load().sgp_reservoir_fused_supported(F, R, L))
+
+
+def reservoir_stack(x, weights, alphas, activation, out, h_state=None):
+    """All layers of a stacked reservoir in one launch: x[T, N, F] -> out[T, N, L*R] (views
+    allowed), ``weights`` = [(w_ih, w_hh, b)] per layer on the device, ``h_state`` [L, N, R]."""
+    lib = require_gpu()
+    xp, xrs, xss = _view3(x, "x")
+    op, ors, oss = _view3(out, "out")
+    T, N, F = x.shape
+    L, R = len(weights), weights[0][1].shape[0]
+    for l, (w_ih, w_hh, b) in enumerate(weights):
+        for name, w, shape in (("w_ih", w_ih, (R, F if l == 0 else R)), ("w_hh", w_hh, (R, R)), ("b", b, (R,))):
+            if tuple(w.shape) != shape or w.dtype != torch.float32 or not w.is_cuda \
+                    or not w.is_contiguous():
+                raise ValueError(f"layer {l} {name}: expected contiguous float32 CUDA {shape}")
+    if out.shape[0] != T or out.shape[1] != N or out.shape[2] != L * R:
+        raise ValueError("out: expected [T, N, L*R]")
+    if h_state is not None and (tuple(h_state.shape) != (L, N, R) or not h_state.is_contiguous()):
+        raise ValueError("h_state: expected contiguous [L, N, R]")
+    wsb = lib.sgp_reservoir_fused_workspace_bytes(F, R, L)
+    if wsb < 0 or not lib.sgp_reservoir_fused_supported(F, R, L):
+        raise NotImplementedError(f"fused reservoir kernel: F={F}, R={R}, L={L} not supported")
+    ws = _workspace(x.device, wsb)
+    ptrs = lambda k: (ctypes.c_void_p * L)(*[w[k].data_ptr() for w in weights])
+    al = (ctypes.c_double * L)(*[float(a) for a in alphas])
+    _check(lib.sgp_reservoir_fused_f32(
+        xp, xrs, xss, ptrs(0), ptrs(1), ptrs(2), al, ACT_CODES[activation], op, ors, oss,
+        h_state.data_ptr() if h_state is not None else None, ws.data_ptr(),
+        T, N, F, R, L, _stream(x)), "sgp_reservoir_fused_f32")
+    return out
+
+
 def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
     """One leaky-ESN layer over all T steps: x[T, N, F] -> out[T, N, R] (views allowed)."""
     lib = require_gpu()
@@ -328,7 +385,7 @@ def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
     if wsb < 0:
         raise NotImplementedError(f"reservoir kernel supports input/hidden sizes <= 256 "
                                   f"(got F={F}, R={R})")
-    ws = torch.empty(wsb // 4, dtype=torch.float32, device=x.device)
+    ws = _workspace(x.device, wsb)
     if h_state is not None and (tuple(h_state.shape) != (N, R) or not h_state.is_contiguous()):
         raise ValueError("h_state: expected contiguous [N, R]")
     _check(lib.sgp_reservoir_f32(

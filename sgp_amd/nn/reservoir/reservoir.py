@@ -149,12 +149,31 @@ class Reservoir(nn.Module):
         step s its input is layer l-1's NEW state of step s, as in reservoir.py:174-176.
         ``h_state``: optional [L, M, R] carried across time chunks."""
         R = self.hidden_size
+        L = len(self.reservoir_layers)
+        if self.fused and L > 1 and self._fusable(x):
+            # all layers in one launch, pipelined as a wavefront (reservoir.py:170-180 steps every
+            # layer inside one time step)
+            weights = [layer._device_weights(x.device) for layer in self.reservoir_layers]
+            hip.reservoir_stack(x, weights, [layer.alpha for layer in self.reservoir_layers],
+                                self.reservoir_layers[0].activation_name, out[:, :, :L * R], h_state)
+            return out
         src = x
         for i, layer in enumerate(self.reservoir_layers):
             dst = out[:, :, i * R:(i + 1) * R]
             layer.run_sequence(src, dst, None if h_state is None else h_state[i])
             src = dst
         return out
+
+    fused = True                    # set False to force one launch per layer
+
+    def _fusable(self, x):
+        """Narrow stacked reservoirs (R * L <= 256: the shipped sgp_pv.yaml has 16 x 8) whose
+        layer-by-layer form is a chain of L x T latency-bound steps; wide layers at large N are
+        throughput-bound and keep the per-layer kernel."""
+        R, L = self.hidden_size, len(self.reservoir_layers)
+        if R * L > 256 or not hip.reservoir_fused_supported(self.input_size, R, L):
+            return False
+        return R <= 32 or x.shape[1] <= 16384
 
     def forward(self, x, h0=None, return_last_state=False):
         # x : b s n f   (reservoir.py:158-186)

@@ -226,6 +226,45 @@ def test_reservoir_long_sequence(n, f, r, L):
     assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize("n,f,r,L,act", [(40, 3, 16, 8, "tanh"), (5016, 3, 16, 8, "tanh"), (333, 5, 32, 4, "relu"),
+                                         (100, 64, 64, 2, "tanh"), (77, 7, 24, 3, "self_norm"),
+                                         (20000, 3, 16, 5, "tanh")])
+def test_fused_multi_layer_reservoir(n, f, r, L, act):
+    """sgp_reservoir_fused_f32 (all layers in one launch, wavefront over the waves of a workgroup;
+    reservoir.py:170-180) agrees with the layer-by-layer kernel (same fp32 products, another
+    summation order in the input part), is bitwise reproducible when the sequence is cut into
+    time chunks with the [L, N, R] state carried on the device, and matches the oracle."""
+    torch.manual_seed(n + L)
+    t = 70
+    # (relu is not contractive at radius 0.95: rounding differences between two summation orders
+    # would grow through 4 layers x 70 steps)
+    res = sgp_amd.Reservoir(f, r, num_layers=L, leaking_rate=0.9, spectral_radius=0.5 if act == "relu" else 0.95,
+                            density=0.7, alpha_decay=True, activation=act)
+    assert hip.reservoir_fused_supported(f, r, L) and res._fusable(torch.empty(1, n, f))
+    x = torch.randn(t, n, f)
+    xg = x.cuda()
+    fused = torch.full((t, n, L * r), float("nan"), device="cuda")
+    res.encode_into(xg, fused)
+    res.fused = False
+    layered = torch.empty_like(fused)
+    res.encode_into(xg, layered)
+    res.fused = True
+    close(fused, layered)
+    state = torch.zeros(L, n, r, device="cuda")
+    chunked = torch.empty_like(fused)
+    for t0 in (0, 1, 30, 31):                              # chunks of 1, 29, 1, 39 steps
+        t1 = {0: 1, 1: 30, 30: 31, 31: t}[t0]
+        res.encode_into(xg[t0:t1], chunked[t0:t1], state)
+    assert torch.equal(chunked, fused)
+    assert torch.equal(state, fused[-1].reshape(n, L, r).permute(1, 0, 2))
+    if n <= 1000:
+        close(fused, O.reservoir_forward(x, layers_of(res), activation=act))
+    # written through a strided slot of a wider buffer (the encoder's output layout)
+    wide = torch.zeros(t, n, 3 * L * r + 4, device="cuda")
+    res.encode_into(xg, wide[:, :, :L * r])
+    assert torch.equal(wide[:, :, :L * r], fused) and float(wide[:, :, L * r:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("act,f,r", [("tanh", 128, 256), ("relu", 128, 256), ("self_norm", 128, 256),
                                      ("tanh", 256, 128)])
 def test_reservoir_wide_streamed_weights(act, f, r):

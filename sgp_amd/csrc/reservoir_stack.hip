@@ -17,10 +17,12 @@
 // CU.  PV-US shape (N = 5016, T = 8868, R = 16 x 8 layers): one chain of 8875 instead of 8 x 8868.
 //
 // The recurrent MFMAs of a step are issued before the input MFMAs, so the LDS read of the
-// producer's state lands under them.  Nothing in an iteration waits for HBM: layer 0 prefetches
-// its input rows PF steps ahead, results are stored at the top of the NEXT step, and the barrier
-// is a bare `s_waitcnt lgkmcnt(0); s_barrier` (hipcc's __syncthreads would drain vmcnt too).
+// producer's state lands under them.  Nothing in an iteration waits for HBM: layer 0 requests
+// its input rows 7 steps ahead by LDS-DMA into a ring, results are stored at the top of the NEXT
+// step, and the barrier is a bare `s_waitcnt lgkmcnt(0); s_barrier` (hipcc's __syncthreads would
+// drain vmcnt too).
 #include "reservoir_impl.h"
+#include <stdlib.h>
 
 namespace {
 using namespace sgp_res;
@@ -34,7 +36,7 @@ struct StackArgs {
     float* out; long long ors, oss;
     float* h_state;                  // [L, N, R] or null
     float alpha[kMaxLayers], oma[kMaxLayers];
-    int act, T, N, F, R, L, ntw, n_tiles;
+    int act, T, N, F, R, L, ntw, n_tiles, debug;
 };
 
 // per-layer block of the packed weights (floats): bias [JT*16] | W_in | W_hh [JT][JT][64][4];
@@ -99,11 +101,13 @@ __global__ void pack_stack(StackPtrs ptr, float* __restrict__ out, int F, int R,
     }
 }
 
-template <int JT, int NKX>
+// OVEC: 16-byte state stores (strides / pointers checked on the host) -- a compile-time switch: with
+// both store flavours in the loop body hipcc's s_waitcnt bookkeeping drains vmcnt(0) every step.
+template <int JT, int NKX, bool OVEC>
 __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
     constexpr int WIN = win_floats(JT, NKX);
     constexpr int LB = layer_floats(JT, NKX);
-    constexpr int PF = NKX <= 4 ? 4 : 2;                 // input rows in flight (layer 0)
+    constexpr int PFD = 8;                               // input-row ring of layer 0 (time steps)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int L = a.L;
     {
@@ -122,6 +126,10 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
     f32x4* ring = reinterpret_cast<f32x4*>(lds + L * LB) + (long long)(ts * L) * 2 * JT * 64;
     f32x4* ring_out = ring + (long long)l * 2 * JT * 64;
     const f32x4* ring_in = ring + (long long)(l > 0 ? l - 1 : 0) * 2 * JT * 64;
+    // input rows of layer 0: [tile slot][PFD][NKX][64] floats, filled by LDS-DMA PFD - 1 steps ahead
+    float* xring = lds + L * LB + (long long)a.ntw * L * 2 * JT * 64 * 4 + (long long)ts * PFD * NKX * 64;
+    const unsigned xring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) float*)xring);
 
     const float* bias = lds + l * LB;
     const float* wx = bias + JT * 16;
@@ -141,16 +149,17 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
         }
         h[jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
     }
-    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
     float* const out_l = a.out + (long long)node * a.ors + (long long)l * a.R;
+    bool st_ok[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) st_ok[jt] = ok && 16 * jt + 4 * q < a.R && !(a.debug & 1);
     auto store_h = [&](int t) {
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) {
             const int j0 = 16 * jt + 4 * q;
-            if (ok && j0 < a.R) {
+            if (st_ok[jt]) {
                 float* op = out_l + (long long)t * a.oss + j0;
-                if (o_vec) {
+                if constexpr (OVEC) {
                     *reinterpret_cast<f32x4*>(op) = h[jt];
                 } else {
 #pragma unroll
@@ -160,28 +169,43 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
             }
         }
     };
-    auto load_x = [&](int t, float (&dst)[NKX]) {
-        const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+    // input rows are requested UNCONDITIONALLY from a clamped address (no branch around a load: a
+    // conditional load makes the compiler wait for it at the join) and masked where they are used
+    bool x_ok[NKX];
+    long long x_off[NKX];
+    {
+        const int nodec = min(node, a.N - 1);
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks)
-            dst[ks] = (ok && t < a.T && q * NKX + ks < a.F) ? xp[ks] : 0.f;
-    };
-    float xq[PF][NKX];                                   // xq[p] = input row of step t + p (layer 0)
-#pragma unroll
-    for (int p = 0; p < PF; ++p)
-#pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xq[p][ks] = 0.f;
-    if (l == 0) {
-#pragma unroll
-        for (int p = 0; p < PF - 1; ++p) load_x(p, xq[p]);
+        for (int ks = 0; ks < NKX; ++ks) {
+            x_ok[ks] = ok && q * NKX + ks < a.F;
+            x_off[ks] = (long long)nodec * a.xrs + min(q * NKX + ks, a.F - 1);
+        }
     }
+    // row of step t -> ring slot t mod PFD.  One global_load_lds_dword per k-step: lane (n, q)
+    // fetches x[node n][q NKX + ks] to slot base + 256 ks + 4 lane.  Issued from inline asm and
+    // waited for with a hand-counted vmcnt: the compiler's own bookkeeping drains vmcnt(0) every
+    // step once loads and (conditional) stores are both pending in the loop.
+    auto dma_x = [&](int t) {
+        const float* xp = a.x + (long long)min(t, a.T - 1) * a.xss;
+        const unsigned base = xring_lds + (unsigned)((t % PFD) * NKX * 256);
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) {
+            const float* src = xp + x_off[ks];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                         :: "v"(src), "s"(base + (unsigned)ks * 256u) : "memory");
+        }
+    };
     __syncthreads();                                     // weights in LDS
+    // retire the set-up loads with a wait the compiler can see (otherwise it carries "may still be
+    // in flight" into the loop and guards every step with vmcnt(0)); layer 0's first rows are
+    // re-requested after it
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0)
+    if (l == 0) {
+        for (int p = 0; p < PFD - 1; ++p) dma_x(p);
+    }
 
     const int n_iter = a.T + L - 1;
-    // one iteration; P = i mod PF is static so that layer 0's input ring needs no register moves
-    // (xq[(P + p) % PF] = row of step t + p; a move would wait for the row requested a moment ago)
-    auto iteration = [&](int i, auto P) {
-        constexpr int P0 = decltype(P)::value;
+    for (int i = 0; i < n_iter; ++i) {
         const int t = i - l;
         if (t >= 0 && t < a.T) {                         // wave-uniform
             // wide layers: keep the fragments in LDS (the compiler would hoist 128 VGPRs of
@@ -198,7 +222,11 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
 #pragma unroll
                 for (int kb = 0; kb < JT; ++kb) hin[kb] = src[kb * 64 + lane];
             } else {
-                load_x(t + PF - 1, xq[(P0 + PF - 1) % PF]);
+                // request row t + PFD - 1 (into the slot consumed one step ago), then wait until at
+                // most the (PFD - 1) NKX youngest memory operations are outstanding: row t is older
+                // than that many requests (stores in between only make the wait stricter)
+                dma_x(t + PFD - 1);
+                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PFD - 1) * NKX < 63 ? (PFD - 1) * NKX : 63) : "memory");
             }
             f32x4 acc[JT];
 #pragma unroll
@@ -218,6 +246,7 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                         acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[jt][s], h[kb][s], acc[jt], 0, 0, 0);
             }
             // input part
+            const float* xrow = xring + (t % PFD) * NKX * 64;
             if (l > 0) {
 #pragma unroll
                 for (int kb = 0; kb < JT; ++kb) {
@@ -239,15 +268,15 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                         const f32x4 wv = *reinterpret_cast<const f32x4*>(wx_t + ((jt * (NKX / 4) + k4) * 64 + lane) * 4);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
-                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xq[P0][4 * k4 + s], acc[jt], 0, 0, 0);
+                            acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], x_ok[4 * k4 + s] ? xrow[(4 * k4 + s) * 64 + lane] : 0.f, acc[jt], 0, 0, 0);
                     }
             } else {
 #pragma unroll
                 for (int ks = 0; ks < NKX; ++ks)
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt)
-                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane], xq[P0][ks],
-                                                                       acc[jt], 0, 0, 0);
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane],
+                                                                       x_ok[ks] ? xrow[ks * 64 + lane] : 0.f, acc[jt], 0, 0, 0);
             }
             if (a.act == SGP_ACT_TANH) {
 #pragma unroll
@@ -283,13 +312,6 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    };
-    // layer 0 has t = i, so slot i mod PF is the row of its current step; the other layers ignore P
-    for (int i0 = 0; i0 < n_iter; i0 += PF) {
-        iteration(i0, IntK<0>{});
-        if constexpr (PF > 1) { if (i0 + 1 < n_iter) iteration(i0 + 1, IntK<1 % PF>{}); }
-        if constexpr (PF > 2) { if (i0 + 2 < n_iter) iteration(i0 + 2, IntK<2 % PF>{}); }
-        if constexpr (PF > 3) { if (i0 + 3 < n_iter) iteration(i0 + 3, IntK<3 % PF>{}); }
     }
     if (a.T > 0) store_h(a.T - 1);
     if (a.h_state) {
@@ -305,7 +327,8 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
 
 template <int JT, int NKX>
 long long stack_lds_bytes(int L, int ntw) {
-    return ((long long)L * layer_floats(JT, NKX) + (long long)ntw * L * 2 * JT * 64 * 4) * 4;
+    return ((long long)L * layer_floats(JT, NKX) + (long long)ntw * L * 2 * JT * 64 * 4 +
+            (long long)ntw * 8 * NKX * 64) * 4;
 }
 
 template <int JT, int NKX>
@@ -320,7 +343,8 @@ int launch_stack(StackArgs a, hipStream_t s) {
     if (stack_lds_bytes<JT, NKX>(a.L, ntw) > kLdsLimit)
         return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: %d layers of %d units exceed the LDS", a.L, a.R);
     a.ntw = ntw;
-    auto kern = reservoir_stack<JT, NKX>;
+    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+    auto kern = ov ? reservoir_stack<JT, NKX, true> : reservoir_stack<JT, NKX, false>;
     const int bytes = (int)stack_lds_bytes<JT, NKX>(a.L, ntw);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -362,7 +386,7 @@ int64_t sgp_reservoir_fused_workspace_bytes(int32_t F, int32_t R, int32_t L) {
 int32_t sgp_reservoir_fused_supported(int32_t F, int32_t R, int32_t L) {
     const int jt = stack_jt(R), nkx = stack_nkx(F);
     if (!jt || !nkx || L < 2 || L > kMaxLayers) return 0;
-    const long long lds = ((long long)L * layer_floats(jt, nkx) + (long long)L * 2 * jt * 64 * 4) * 4;
+    const long long lds = ((long long)L * layer_floats(jt, nkx) + (long long)L * 2 * jt * 64 * 4 + 8ll * nkx * 64) * 4;
     return lds <= kLdsLimit ? 1 : 0;
 }
 
@@ -405,6 +429,7 @@ int sgp_reservoir_fused_f32(const float* x, int64_t xrs, int64_t xss,
         a.oma[l] = (float)(1.0 - al);              // `(1 - alpha) * h` (reservoir.py:80)
     }
     a.act = act; a.T = T; a.N = N; a.F = F; a.R = R; a.L = L; a.ntw = 1; a.n_tiles = 0;
+    { const char* e = getenv("SGP_STACK_DEBUG"); a.debug = e ? atoi(e) : 0; }   // bit 0: skip the result stores (timing ablation)
     switch (jt) {
         case 1: return launch_stack_nkx<1>(a, nkx, s);
         case 2: return launch_stack_nkx<2>(a, nkx, s);

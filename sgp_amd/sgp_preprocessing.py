@@ -97,10 +97,18 @@ def sgp_spatial_embedding(x,
                           dropout_rate=0.):
     """lib/sgp_preprocessing.py:163-218: ``[x, A x, ..., A^k x (, A_b x, ..., A_b^k x)]``
     as a list of views into one fused ``[B, N, P * F]`` buffer."""
+    if dropout_rate < 0. or dropout_rate > 1.:
+        raise ValueError(f"Dropout probability has to be between 0 and 1 (got {dropout_rate})")
     if dropout_rate != 0.:
-        # torch_geometric.utils.dropout_adj with p > 0 draws an edge mask from the RNG
-        # (sgp_preprocessing.py:177-179); no caller in the reference enables it.
-        raise NotImplementedError("dropout_rate > 0 is not supported")
+        # torch_geometric.utils.dropout_adj (sgp_preprocessing.py:177-179): one bernoulli draw
+        # over E entries of value 1 - p on the host RNG keeps the surviving edges; the backward
+        # operator is built from the same thinned list (:203-204)
+        if _is_sparse_like(edge_index):
+            raise NotImplementedError("dropout_rate > 0 needs an edge_index tensor")
+        ei = torch.as_tensor(edge_index).cpu()
+        keep = torch.bernoulli(torch.full((ei.shape[1],), 1. - dropout_rate, dtype=torch.float)).to(torch.bool)
+        edge_index = ei[:, keep]
+        edge_weight = None if edge_weight is None else torch.as_tensor(edge_weight).cpu()[keep]
     ops = spatial_operators(edge_index, edge_weight, num_nodes, undirected=undirected,
                             add_self_loops=add_self_loops,
                             remove_self_loops=remove_self_loops,

@@ -13,14 +13,20 @@ logger = logging.getLogger("sgp_amd")
 
 
 def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True,
-                   keep_raw=False, save_path=None):
+                   keep_raw=False, save_path=None, return_device=False):
     """lib/utils.py:10-47.  ``dataset`` is any object with the slice of the
     ``tsl.data.SpatioTemporalDataset`` interface the harness touches: ``exogenous``,
     ``get_tensors``, ``edge_index``, ``edge_weight``, ``add_exogenous``, ``set_input_map``.
 
     The reference leaves ``preprocess_exogenous`` unbound when ``encode_exogenous`` is not a
     bool (lib/utils.py:19-22 -> UnboundLocalError); a list is accepted here and treated as the
-    list of exogenous keys to encode."""
+    list of exogenous keys to encode.
+
+    Beyond the reference: ``return_device=True`` leaves ``encoded_x`` on the GPU (no 36-630 GB
+    host round trip before the IID sampler); with ``save_path`` the encoder's
+    constructor arguments, per-layer leaking rates and weights are written next to the tensor
+    (``save_path + '.encoder.pt'``) so that the embedding can be re-derived (lib/utils.py:34-35
+    saves the tensor only, the random weights are lost)."""
     if isinstance(encode_exogenous, bool):
         preprocess_exogenous = dataset.exogenous.keys() if encode_exogenous else []
     else:
@@ -32,11 +38,17 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     encoder = encoder_class(**encoder_kwargs)
 
     start = time()
+    if return_device:                 # every encoder answers on the device of its input
+        from . import hip
+        hip.require_gpu()
+        x = x.cuda()
     encoded_x = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight)
     elapsed = int(time() - start)
 
     if save_path is not None:
         torch.save(encoded_x, save_path)
+        if hasattr(encoder, "describe"):
+            torch.save(encoder.describe(), str(save_path) + ".encoder.pt")
 
     logger.info(f"Dataset encoded in {elapsed // 60}:{elapsed % 60:02d} minutes.")
 

@@ -77,10 +77,8 @@ def test_spmm_csr_strided_slots_in_place():
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
-        x = ref[:, :, :d].cpu()
-        for k in range(1, p):
-            x = dense_ref(op, x)
-            close(out[:, :, k * d:(k + 1) * d], x, rtol=2e-5, atol=2e-5, fro=2e-5)
+        for k in range(1, p):        # every hop against the exact product of the slot it read
+            close(out[:, :, k * d:(k + 1) * d], dense_ref(op, out[:, :, (k - 1) * d:k * d]))
         assert torch.equal(out[:, :, :d], ref[:, :, :d])
 
 
@@ -829,3 +827,226 @@ def test_spatial_supports_propagate_on_gpu():
     for s, r in zip(sup, torch.from_numpy(z["supports"])):
         got = (s @ x.cuda()).cpu() if not torch.is_tensor(s) else s @ x
         close(got, torch.einsum("ij,tjf->tif", r, x))
+
+
+# ------------------------------------------------------------------ BASELINE configs at their own shapes
+def _hop_property_checks(out, d_h, ops, k, steps):
+    """Size-independent checks on a full-size embedding: every hop block equals the operator
+    applied to the block it read (generic CSR kernel as the second opinion), on sampled steps."""
+    for d, op in enumerate(ops):
+        for h in range(k):
+            s_src = 0 if h == 0 else 1 + d * k + h - 1
+            s_dst = 1 + d * k + h
+            src = out[steps][:, :, s_src * d_h:(s_src + 1) * d_h].contiguous()
+            ref = torch.empty_like(src)
+            op.propagate(src, ref, force="csr")
+            close(out[steps][:, :, s_dst * d_h:(s_dst + 1) * d_h], ref, rtol=1e-5, atol=1e-5, fro=2e-6)
+
+
+def test_config_c3_at_its_own_shape():
+    """BASELINE configs[2]: N = 10 000, 100-NN, T = 2016, F = 64, R = 64, K = 4, one MI355X.
+    Whole sequence on the device; the first 48 steps against the oracle (sparse operators), the
+    rest through size-independent properties: hop blocks consistent at sampled steps, state
+    continuity (encoding steps 1000.. from the carried state reproduces the tail bit for bit)."""
+    from sgp_amd.sgp_preprocessing import spatial_operators
+    torch.manual_seed(3)
+    n, t, f, k = 10000, 2016, 64, 4
+    ei, ew, _ = synthetic.knn_graph(n, 100, seed=1)
+    enc = sgp_amd.SGPEncoder(input_size=f, reservoir_size=64, reservoir_layers=1, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=k,
+                             bidirectional=False, alpha_decay=False, global_attr=False)
+    x = torch.randn(t, n, f)
+    xg = x.cuda()
+    out = enc(xg, ei, ew)
+    assert out.shape == (t, n, 320) and out.is_cuda
+    ops = spatial_operators(ei, ew, n)
+    probe = torch.empty(1, n, 64, device="cuda")
+    ops[0].propagate(out[:1, :, :64], probe)
+    assert ops[0].last_kernel in ("spmm_res", "spmm_pipe") and torch.equal(probe, out[:1, :, 64:128])
+    ref = O.sgp_encoder_forward(x[:48], ei, ew, layers_of(enc.reservoir), k, sparse=True)
+    close(out[:48], ref)
+    steps = torch.tensor([0, 47, 48, 1000, 2015], device="cuda")
+    _hop_property_checks(out, 64, ops, k, steps)
+    assert torch.isfinite(out[-1]).all() and float(out[:, :, :64].abs().max()) <= 1.0   # tanh states
+    state = out[999, :, :64].clone()[None].contiguous()                # h(999) as [L, N, R]
+    tail = torch.empty(t - 1000, n, 64, device="cuda")
+    enc.reservoir.encode_into(xg[1000:], tail, state)
+    assert torch.equal(tail, out[1000:, :, :64])
+
+
+def test_config_c4_pv_us_flag_set():
+    """BASELINE configs[3] on one GPU: N = 5016, 100-NN, the shipped large-scale flag set
+    (config/largescale_100nn/sgp_pv.yaml:10-24: 16 units x 8 layers, leaking rate 1.0 decaying,
+    radius 0.99, K = 2, global_attr) -- the fused multi-layer reservoir + two 128-wide hops +
+    the global mean -- against the oracle."""
+    torch.manual_seed(4)
+    n, t = 5016, 96
+    ei, ew, _ = synthetic.knn_graph(n, 100, seed=1)
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=16, reservoir_layers=8, leaking_rate=1.0,
+                             spectral_radius=.99, density=.7, input_scaling=1., receptive_field=2,
+                             bidirectional=False, alpha_decay=True, global_attr=True)
+    x = torch.randn(t, n, 3)
+    out = enc(x.cuda(), ei, ew)
+    assert out.shape == (t, n, 4 * 128)
+    ref = O.sgp_encoder_forward(x, ei, ew, layers_of(enc.reservoir), 2, global_attr=True, sparse=True)
+    close(out, ref)
+
+
+def test_config_c5_end_to_end_on_one_gpu():
+    """BASELINE configs[4] (N = 100 000, 100-NN, F = 128, R = 256, K = 5) end to end on one GPU at
+    reduced T: host tensor in, host tensor out through the pipelined time-chunk path with the
+    reservoir state carried on the device (how the 629 GB embedding is produced on < 4 GPUs),
+    bit-identical to one device pass; the first steps against the oracle, hop blocks checked
+    against the generic CSR kernel."""
+    from sgp_amd.sgp_preprocessing import spatial_operators
+    torch.manual_seed(5)
+    n, t, f, r, k = 100000, 6, 128, 256, 5
+    ei, ew, _ = synthetic.knn_graph(n, 100, seed=1)
+    enc = sgp_amd.SGPEncoder(input_size=f, reservoir_size=r, reservoir_layers=1, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=k,
+                             bidirectional=False, alpha_decay=False, global_attr=False)
+    x = torch.randn(t, n, f)
+    ops = spatial_operators(ei, ew, n)
+    host = enc.encode_streamed(x, ops, 2)                   # 3 chunks of 2 steps
+    assert not host.is_cuda and not host.is_pinned() and host.shape == (t, n, 6 * r)
+    dev = enc(x.cuda(), ei, ew)
+    assert torch.equal(host, dev.cpu())
+    ref = O.sgp_encoder_forward(x[:2], ei, ew, layers_of(enc.reservoir), k, sparse=True)
+    close(host[:2], ref)
+    _hop_property_checks(dev, r, ops, k, torch.tensor([2, 5], device="cuda"))
+
+
+def test_pipelined_host_streaming_paths():
+    """encode_streamed: ragged last chunk, a single chunk, pinned input, non-float input, and the
+    automatic choice in forward() for host inputs -- all bit-identical to the device pass."""
+    torch.manual_seed(12)
+    n, t = 500, 45
+    ei, ew, _ = synthetic.knn_graph(n, 12, seed=5)
+    enc = sgp_amd.SGPEncoder(input_size=5, reservoir_size=32, reservoir_layers=2, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=2,
+                             bidirectional=True, alpha_decay=True, global_attr=True)
+    x = torch.randn(t, n, 5)
+    full = enc(x.cuda(), ei, ew).cpu()
+    ops = enc.sgp_encoder.operators(n, ei, ew)
+    for tc in (1, 7, 44, 45, 100):
+        assert torch.equal(enc.encode_streamed(x, ops, tc), full)
+    assert torch.equal(enc.encode_streamed(x.pin_memory(), ops, 8), full)
+    assert torch.equal(enc.encode_streamed(x.double(), ops, 8), enc(x.double().float().cuda(), ei, ew).cpu())
+    enc.stream_threshold_bytes = 1 << 16                     # forward() takes the pipelined path
+    enc.stream_chunk_bytes = 1 << 18
+    auto = enc(x, ei, ew)
+    assert not auto.is_cuda and torch.equal(auto, full)
+    assert enc(x, ei, ew, return_device=True).is_cuda
+
+
+# ------------------------------------------------------------------ legacy API rows (R6, S7) and S2's flags
+def test_forward_prealloc_is_the_recurrence():
+    """lib/nn/reservoir/reservoir.py:131-156 is dead code with a read-before-write bug in the
+    reference; the name is kept and must give the recurrence of ``forward``."""
+    torch.manual_seed(1)
+    res = sgp_amd.Reservoir(3, 16, num_layers=2, alpha_decay=True)
+    x = torch.randn(2, 9, 11, 3)
+    close(res.forward_prealloc(x), res(x), rtol=0, atol=0)
+    h0 = torch.randn(2, 2, 11, 16)
+    close(res.forward_prealloc(x, h0, return_last_state=True), res(x, h0, return_last_state=True), rtol=0, atol=0)
+    close(res.forward_prealloc(x[0]), res(x[:1])[0], rtol=0, atol=0)      # [s n f] input
+    close(res(x[:1])[0], O.reservoir_forward(x[0], layers_of(res)))
+
+
+def test_legacy_preprocess_dataset_and_reservoir_preprocessing():
+    """lib/sgp_preprocessing.py:15-64 (uncalled in the reference, part of the exported surface)."""
+    from test_host_logic import FakeDataset
+    from sgp_amd.sgp_preprocessing import preprocess_dataset, reservoir_preprocessing_
+    torch.manual_seed(2)
+    n, t = 30, 20
+    ei, ew, _ = synthetic.knn_graph(n, 5, seed=2)
+    data, u = torch.randn(t, n, 1), torch.randn(t, 2)
+    rk = dict(hidden_size=16, num_layers=2, leaking_rate=0.8, spectral_radius=0.9, density=0.7)
+    torch.manual_seed(77)
+    got = reservoir_preprocessing_(data, **rk)
+    torch.manual_seed(77)
+    twin = sgp_amd.Reservoir(input_size=1, **rk)             # same seed -> same weights
+    close(got, O.reservoir_forward(data, layers_of(twin)))
+    ds = FakeDataset(data, u, ei, ew)
+    torch.manual_seed(78)
+    preprocess_dataset(ds, True, rk, dict(k=2, bidirectional=True))
+    torch.manual_seed(78)
+    twin = sgp_amd.Reservoir(input_size=3, **rk)
+    xin = torch.cat([data, u[:, None].expand(-1, n, -1)], -1)
+    h = O.reservoir_forward(xin, layers_of(twin))
+    ref = torch.cat(O.spatial_embedding(h, ei, ew, k=2, bidirectional=True), -1)
+    close(ds._t["processed_x"], ref)
+    assert ds.input_map == {"x": ["processed_x"]}
+    assert ("add_exogenous", "processed_x", False) in ds.calls
+
+
+def test_spatial_embedding_one_hot_and_edge_dropout():
+    """S2's remaining flags (lib/sgp_preprocessing.py:177-179, 194-197): node identities appended
+    before the hops (feature width F + N: the scalar CSR path), and the Bernoulli edge mask of
+    ``dropout_adj`` drawn from the host RNG exactly once."""
+    torch.manual_seed(3)
+    n, f = 40, 3
+    ei, ew, _ = synthetic.knn_graph(n, 6, seed=3)
+    x = torch.randn(4, n, f)
+    for kw in (dict(one_hot_encoding=True), dict(one_hot_encoding=True, bidirectional=True),
+               dict(one_hot_encoding=True, undirected=True, add_self_loops=True)):
+        got = sgp_amd.sgp_spatial_embedding(x, n, ei, ew, k=2, **kw)
+        ref = O.spatial_embedding(x, ei, ew, k=2, **kw)
+        assert len(got) == len(ref) and got[0].shape[-1] == f + n
+        for g, r in zip(got, ref):
+            close(g, r)
+    for kw in (dict(dropout_rate=0.3), dict(dropout_rate=0.5, bidirectional=True)):
+        torch.manual_seed(9)
+        got = sgp_amd.sgp_spatial_embedding(x, n, ei, ew, k=2, **kw)
+        after = torch.rand(1)
+        torch.manual_seed(9)
+        ref = O.spatial_embedding(x, ei, ew, k=2, **kw)
+        assert torch.equal(after, torch.rand(1))             # same RNG consumption
+        for g, r in zip(got, ref):
+            close(g, r)
+    with pytest.raises(ValueError):
+        sgp_amd.sgp_spatial_embedding(x, n, ei, ew, dropout_rate=1.5)
+
+
+def test_operator_shape_validation_and_row_subset_matmul():
+    """ADVICE: operands with the wrong node count raise instead of reading out of bounds, and
+    ``adj.index_select(0, idx) @ x`` (lib/datasets/iid_dataset.py:113) gives the row subset."""
+    torch.manual_seed(4)
+    n = 300
+    ei, ew, _ = synthetic.knn_graph(n, 8, seed=4)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    x = torch.randn(2, n, 64, device="cuda")
+    with pytest.raises(ValueError):
+        op.propagate(x[:, :-1], torch.empty(2, n, 64, device="cuda"))
+    with pytest.raises(ValueError):
+        op.propagate(x, torch.empty(2, n + 1, 64, device="cuda"))
+    with pytest.raises(ValueError):
+        op @ x[:, :-3]
+    with pytest.raises(ValueError):
+        sgp_amd.sgp_spatial_embedding(x.cpu(), n + 5, ei, ew)
+    idx = torch.tensor([5, 17, 5, 299, 0])
+    sub = op.index_select(0, idx)
+    close(sub @ x, dense_ref(op, x.cpu())[:, idx])
+
+
+def test_encode_dataset_saves_what_makes_the_embedding_rederivable(tmp_path):
+    """lib/utils.py:34-35 saves the tensor only; here the encoder's arguments, leaking rates and
+    weights go next to it, and ``return_device=True`` keeps the embedding on the GPU."""
+    from test_host_logic import FakeDataset
+    torch.manual_seed(6)
+    n, t = 25, 12
+    ei, ew, _ = synthetic.knn_graph(n, 4, seed=6)
+    ds = FakeDataset(torch.randn(t, n, 1), torch.randn(t, 2), ei, ew)
+    kw = dict(input_size=3, reservoir_size=16, reservoir_layers=2, leaking_rate=.9, spectral_radius=.9,
+              density=.7, input_scaling=1., receptive_field=2, bidirectional=True, alpha_decay=True,
+              global_attr=True)
+    path = tmp_path / "emb.pt"
+    sgp_amd.encode_dataset(ds, sgp_amd.SGPEncoder, kw, save_path=str(path), return_device=True)
+    emb = ds._t["encoded_x"]
+    assert emb.is_cuda and torch.equal(torch.load(path).cpu(), emb.cpu())
+    desc = torch.load(str(path) + ".encoder.pt")
+    assert desc["kwargs"]["reservoir_layers"] == 2 and desc["alphas"] == pytest.approx([0.9, 0.8])
+    twin = sgp_amd.SGPEncoder(**desc["kwargs"])
+    twin.load_state_dict(desc["state_dict"])
+    x, _ = ds.get_tensors(["data", "u"], preprocess=True, cat_dim=-1)
+    assert torch.equal(twin(x.cuda(), ei, ew), emb)

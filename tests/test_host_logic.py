@@ -354,3 +354,43 @@ def test_gesn_encoder_surface():
         sgp_amd.GESNLayer(3, 8, aggr="mean")
     enc = sgp_amd.GESNEncoder(3, 8, 2, .9, .9, .7, 1., True)
     assert [float(c.alpha) for c in enc.reservoir.rnn_cells] == [.9, .8]
+
+
+def test_matmul_checks_the_node_count_before_touching_a_device():
+    """ADVICE: an operand with the wrong node count is a ValueError (the reference raises a shape
+    error), not an out-of-bounds read -- checked on the host, before the GPU is required."""
+    from sgp_amd import graph
+    op = graph.ShiftOperator.from_edges(torch.tensor([[0, 1, 2], [1, 2, 0]]), None, 3)
+    with pytest.raises(ValueError):
+        op @ torch.randn(2, 4, 8)
+    with pytest.raises(TypeError):
+        op @ 3.0
+
+
+def test_encode_dataset_return_device_requires_the_gpu_and_describe_is_optional(tmp_path):
+    from sgp_amd import hip
+    ds = FakeDataset(torch.randn(6, 4, 1), torch.randn(6, 2), torch.tensor([[0, 1], [1, 2]]), None)
+    path = tmp_path / "e.pt"
+    sgp_amd.encode_dataset(ds, StubEncoder, dict(input_size=3), save_path=str(path))
+    assert path.exists() and not (tmp_path / "e.pt.encoder.pt").exists()     # stub has no describe()
+    if not (torch.cuda.is_available() and hip.load() is not None):
+        with pytest.raises(RuntimeError):
+            sgp_amd.encode_dataset(ds, StubEncoder, dict(input_size=3), return_device=True)
+
+
+def test_encoder_describe_round_trips_without_a_gpu():
+    enc = sgp_amd.SGPEncoder(input_size=2, reservoir_size=8, reservoir_layers=3, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=2,
+                             bidirectional=True, alpha_decay=True, global_attr=True)
+    d = enc.describe()
+    twin = sgp_amd.SGPEncoder(**d["kwargs"])
+    twin.load_state_dict(d["state_dict"])
+    assert d["alphas"] == pytest.approx([0.9, 0.8, 0.7])
+    for a, b in zip(enc.parameters(), twin.parameters()):
+        assert torch.equal(a, b)
+    assert twin.output_size == enc.output_size
+
+
+def test_dropout_rate_is_validated_like_dropout_adj():
+    with pytest.raises(ValueError):
+        sgp_amd.sgp_spatial_embedding(torch.randn(1, 3, 2), 3, torch.tensor([[0, 1], [1, 2]]), dropout_rate=-0.1)

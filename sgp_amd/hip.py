@@ -167,6 +167,25 @@ def _check(rc, what):
         raise kind(f"{what} failed (code {rc}): {msg}")
 
 
+def _on_device(fn):
+    """Run a binding under the device of its first CUDA tensor argument: the launches go to that
+    device's current stream, and helper calls inside the library (memsets, copies, event records)
+    follow the process's CURRENT device -- a tensor on cuda:1 while cuda:0 is current would
+    otherwise mix devices."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        for a in list(args) + list(kw.values()):
+            if torch.is_tensor(a) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    break
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kw)
+        return fn(*args, **kw)
+    return wrapped
+
+
 def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
@@ -185,6 +204,7 @@ MAX_GRID_BATCH = 65535
 
 
 # ---------------------------------------------------------------- SpMM
+@_on_device
 def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
     """y[b, i, :] = sum_e val[e] x[b, col[e], :] (generic CSR kernel)."""
     lib = require_gpu()
@@ -198,7 +218,11 @@ def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
     else:
         hp, hrs, hbs, n_own = None, 0, 0, n_cols
     B, D = x.shape[0], x.shape[2]
-    step = 4 * MAX_GRID_BATCH
+    # the vector kernel walks 4 batch entries per grid row; feature widths / strides that are not
+    # multiples of 4 floats (or unaligned pointers) take the scalar kernel: one entry per grid row
+    vec = D % 4 == 0 and all(v % 4 == 0 for v in (xrs, xbs, yrs, ybs, hrs, hbs)) and \
+        all((ptr or 0) % 16 == 0 for ptr in (xp, yp, hp))
+    step = (4 if vec else 1) * MAX_GRID_BATCH
     for b0 in range(0, B, step):
         nb = min(step, B - b0)
         _check(lib.sgp_spmm_csr_f32(
@@ -209,6 +233,7 @@ def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
             n_rows, n_cols, nb, D, _stream(x)), "sgp_spmm_csr_f32")
 
 
+@_on_device
 def spmm_tiled(plan, x, y, halo=None, n_own=None):
     """Same product through the LDS-staged kernel; ``plan`` from graph.TilePlan.to(device)."""
     lib = require_gpu()
@@ -228,6 +253,7 @@ def spmm_tiled(plan, x, y, halo=None, n_own=None):
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_tiled_f32")
 
 
+@_on_device
 def spmm_mfma(plan, x, y, halo=None, n_own=None):
     """Row-group product on the matrix cores (v_mfma_f32_4x4x1_16b_f32)."""
     lib = require_gpu()
@@ -247,6 +273,7 @@ def spmm_mfma(plan, x, y, halo=None, n_own=None):
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mfma_f32")
 
 
+@_on_device
 def spmm_pipe(plan, x, y, halo=None, n_own=None):
     """Two-phase pipelined row-group product (LDS-DMA staging, v_mfma_f32_4x4x1_16b_f32)."""
     lib = require_gpu()
@@ -268,6 +295,7 @@ def spmm_pipe(plan, x, y, halo=None, n_own=None):
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_pipe_f32")
 
 
+@_on_device
 def spmm_res(plan, x, y, halo=None, n_own=None):
     """Register-resident two-phase row-group product (same plan and results as spmm_pipe)."""
     lib = require_gpu()
@@ -289,6 +317,7 @@ def spmm_res(plan, x, y, halo=None, n_own=None):
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_res_f32")
 
 
+@_on_device
 def spmm_blk(plan, x, y, halo=None, n_own=None):
     """Row-block product (plan: sgp_amd.rowblock.RowBlockPlan on the device of ``x``)."""
     lib = require_gpu()
@@ -338,6 +367,7 @@ def reservoir_fused_supported(F, R, L):
     return bool(load().sgp_reservoir_fused_supported(F, R, L))
 
 
+@_on_device
 def reservoir_stack(x, weights, alphas, activation, out, h_state=None):
     """All layers of a stacked reservoir in one launch: x[T, N, F] -> out[T, N, L*R] (views
     allowed), ``weights`` = [(w_ih, w_hh, b)] per layer on the device, ``h_state`` [L, N, R]."""
@@ -368,6 +398,7 @@ def reservoir_stack(x, weights, alphas, activation, out, h_state=None):
     return out
 
 
+@_on_device
 def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
     """One leaky-ESN layer over all T steps: x[T, N, F] -> out[T, N, R] (views allowed)."""
     lib = require_gpu()
@@ -397,6 +428,7 @@ def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
 
 
 # ---------------------------------------------------------------- DynGESN
+@_on_device
 def gesn_sequence(rowptr, col, val, x, weights, alphas, activation, out, h_state):
     """Whole DynGESN sequence: x[T, N, F] -> out[T, N, L*R]; ``weights`` is a list of
     (w_ih, w_hh, b) device tensors per layer, ``h_state`` [L, N, R] is updated in place."""
@@ -421,6 +453,7 @@ def gesn_sequence(rowptr, col, val, x, weights, alphas, activation, out, h_state
     return out
 
 
+@_on_device
 def gemm_nt(a, w, bias, out):
     """out[m, n] = sum_k a[m, k] w[n, k] (+ bias[n]); 2-D float32 CUDA, unit inner strides."""
     lib = require_gpu()
@@ -433,6 +466,7 @@ def gemm_nt(a, w, bias, out):
     return out
 
 
+@_on_device
 def gesn_update(rowptr, col, val, z, p, h_in, alpha, activation, h_out, out_rows):
     """DynGESN state update for one (step, layer); ``out_rows`` is the [N, R] slot (row stride
     arbitrary) of the embedding that receives the new state."""
@@ -454,6 +488,7 @@ def _batched(fn, B):
         fn(b0, min(MAX_GRID_BATCH, B - b0))
 
 
+@_on_device
 def node_mean_bcast(x, y):
     """y[b, i, :] = mean_j x[b, j, :] for every node i (global_attr block)."""
     lib = require_gpu()
@@ -470,6 +505,7 @@ def node_mean_bcast(x, y):
     return y
 
 
+@_on_device
 def node_sums(x):
     """[B, D] un-normalised column sums (multi-GPU: all-reduce these, then bcast_rows)."""
     lib = require_gpu()
@@ -485,6 +521,7 @@ def node_sums(x):
     return out
 
 
+@_on_device
 def bcast_rows(src, scale, y):
     lib = require_gpu()
     yp, yrs, ybs = _view3(y, "y")
@@ -499,6 +536,7 @@ def bcast_rows(src, scale, y):
     return y
 
 
+@_on_device
 def copy_rows(x, y):
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
@@ -512,6 +550,7 @@ def copy_rows(x, y):
     return y
 
 
+@_on_device
 def gather_nodes(x, node_index, out=None):
     """out[b, k, :] = x[b, node_index[k], :] (halo packing)."""
     lib = require_gpu()
@@ -530,6 +569,7 @@ def gather_nodes(x, node_index, out=None):
     return out
 
 
+@_on_device
 def gather_rows(x, step_index, node_index):
     """out[k, :] = x[step_index[k], node_index[k], :] (IID sampling of the embedding)."""
     lib = require_gpu()
@@ -544,6 +584,7 @@ def gather_rows(x, step_index, node_index):
 GL_ACT_CODES = {None: 0, "linear": 0, "identity": 0, "relu": 1, "silu": 2}
 
 
+@_on_device
 def grouped_linear_pack(weight, groups):
     """Conv1d weight [groups*oc, ic(, 1)] (CUDA) -> MFMA fragment order."""
     lib = require_gpu()
@@ -556,6 +597,7 @@ def grouped_linear_pack(weight, groups):
     return packed
 
 
+@_on_device
 def grouped_linear(x2, packed, bias, groups, ic, oc, activation, step_index=None, node_index=None,
                    source=None):
     """rows [K, groups*ic] -> [K, groups*oc]; with (step_index, node_index) the rows are gathered

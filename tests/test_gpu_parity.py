@@ -1050,3 +1050,18 @@ def test_encode_dataset_saves_what_makes_the_embedding_rederivable(tmp_path):
     twin.load_state_dict(desc["state_dict"])
     x, _ = ds.get_tensors(["data", "u"], preprocess=True, cat_dim=-1)
     assert torch.equal(twin(x.cuda(), ei, ew), emb)
+
+
+def test_spmm_csr_scalar_path_long_batch():
+    """ADVICE: raw F = 3 features over more than 65 535 steps take the scalar CSR kernel, whose
+    grid holds one batch entry per row -- the binding chunks it instead of raising."""
+    torch.manual_seed(13)
+    n, t, f = 12, 70001, 3
+    ei = torch.randint(0, n, (2, 40))
+    op = graph.ShiftOperator.from_edges(ei, torch.rand(40) + .1, n)
+    x = torch.randn(t, n, f)
+    y = torch.full((t, n, f), float("nan"), device="cuda")
+    op.propagate(x.cuda(), y, force="csr")
+    close(y[-3:], dense_ref(op, x[-3:]))
+    close(y[65534:65537], dense_ref(op, x[65534:65537]))
+    assert torch.isfinite(y).all()

@@ -15,6 +15,8 @@ with torch CPU ops; only the resulting arrays travel to the GPU.
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -220,9 +222,6 @@ class ShiftOperator:
                 return y
         if force == "blk":
             raise NotImplementedError("no row-block plan for this graph / feature width")
-        if plan is not None and halo is not None and \
-                halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 31:
-            plan = None                      # tiled kernels use 32-bit row offsets
         if force in ("tiled", "mfma", "pipe", "res") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
         if force == "mfma" and (plan is None or plan.gw is None):
@@ -373,6 +372,13 @@ def split_tiles(rowptr, col, n_rows, tile_rows, max_union, min_rows=8):
     trow = np.arange(0, n_rows + tile_rows, tile_rows, dtype=np.int64)
     trow[-1] = n_rows
     trow = np.unique(trow)
+    return refine_tiles(rowptr, col, trow, max_union, min_rows)
+
+
+def refine_tiles(rowptr, col, trow, max_union, min_rows=8):
+    """Halve every tile of ``trow`` that references more than ``max_union`` distinct columns until
+    all fit; None if a tile of ``min_rows`` rows still does not."""
+    trow = np.unique(np.asarray(trow, dtype=np.int64))
     while True:
         uptr, _, _, _ = tile_unions(rowptr, col, trow)
         over = np.nonzero(np.diff(uptr) > max_union)[0]
@@ -734,8 +740,50 @@ def build_reordered_plan(rowptr, col, val, n_rows, order, **limits):
     return plan
 
 
+def equal_cost_tiles(rowptr, col, n_rows, trow, tile_cost, max_rows, max_union, quantile=0.15):
+    """Tile boundaries with (about) EQUAL cost per tile.  Workgroups of an XCD that take the same
+    time per step stay on the same time steps, and the staged rows they share are then read from
+    the L2 instead of the fabric: with uniform 64-row tiles the cost of a step varies
+    by +-20 % (and by 2x for tiles halved at the LDS limit), the workgroups drift ~8 steps apart
+    and half of the staging reads miss.  ``tile_cost`` = critical super-steps per step of the
+    current tiles; the per-row cost density derived from it is re-cut greedily into runs of
+    ``target`` cost (the ``quantile`` of the full tiles' costs: cheaper regions keep ``max_rows``
+    rows, dearer ones get fewer), then halved where the LDS limit still bites."""
+    trow = np.asarray(trow, dtype=np.int64)
+    rows = np.diff(trow)
+    cost = np.asarray(tile_cost, dtype=np.float64)
+    full = rows == rows.max()
+    if not full.any():
+        return trow
+    target = float(np.quantile(cost[full], quantile))
+    dens = np.repeat(cost / np.maximum(rows, 1), rows)            # cost per row
+    cum = np.concatenate([[0.0], np.cumsum(dens)])
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col)
+    stamp = np.full(int(col.max()) + 1 if col.size else 1, -1, dtype=np.int64)
+    cuts = [0]
+    r, tid = 0, 0
+    while r < n_rows:
+        # grow the tile 4 rows (one row group) at a time while it stays within the cost target,
+        # the row limit and the LDS limit on distinct source rows
+        end, union = r, 0
+        while end < n_rows and end - r < max_rows:
+            nxt = min(n_rows, end + 4)
+            cols = np.unique(col[rowptr[end]:rowptr[nxt]])
+            fresh = cols[stamp[cols] != tid]
+            if end > r and (union + fresh.size > max_union or cum[nxt] - cum[r] > target * 1.0001):
+                break
+            stamp[fresh] = tid
+            union += fresh.size
+            end = nxt
+        cuts.append(end)
+        r, tid = end, tid + 1
+    return refine_tiles(rowptr, col, np.asarray(cuts, dtype=np.int64), max_union)
+
+
 def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_edges,
-                    candidates=(64, 32, 16), cluster=True) -> Optional[TilePlan]:
+                    candidates=(64, 32, 16), cluster=True, trow_override=None,
+                    equalize=None) -> Optional[TilePlan]:
     """Tallest tiling whose per-tile working set fits the LDS stage, or None when the
     graph has no locality to exploit (average tile would stage more than it reuses)."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
@@ -752,11 +800,14 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
         # the 4-rows-per-group x 8-batch kernel variant spills; keep tall tiles for short rows
         if tr > 64 and mre > 32:
             continue
-        trow = split_tiles(rowptr, col, n_rows, tr, min(max_union, 65535))
+        if trow_override is not None:
+            trow = np.asarray(trow_override, dtype=np.int64)
+        else:
+            trow = split_tiles(rowptr, col, n_rows, tr, min(max_union, 65535))
         if trow is None:
             continue
         n_tiles = len(trow) - 1
-        if n_tiles > 1.5 * ((n_rows + tr - 1) // tr) + 1:
+        if trow_override is None and n_tiles > 1.5 * ((n_rows + tr - 1) // tr) + 1:
             continue                       # mostly split: a smaller uniform height is better
         uptr, ucol, lcol, row_of_edge = tile_unions(rowptr, col, trow)
         mu = int(np.diff(uptr).max())
@@ -790,6 +841,19 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                              gidx=torch.from_numpy(ps["gidx"]), gw=torch.from_numpy(ps["gw"]),
                              rowmap=torch.from_numpy(ps["rowmap"]), fill=ps["fill"],
                              max_tile_quads=ps["max_tile_quads"],
-                             max_range_steps=ps["max_range_steps"])
+                             max_range_steps=ps["max_range_steps"],
+                             phase_cost=ps["phase_cost"])
+            if equalize is None:
+                equalize = os.environ.get("SGP_EQUAL_COST_TILES", "0") == "1"
+            if equalize and trow_override is None and tr == 64 and n_tiles >= 512:
+                new_trow = equal_cost_tiles(rowptr, col, n_rows, trow, ps["phase_cost"], tr,
+                                            min(max_union, 65535),
+                                            float(os.environ.get("SGP_EQUAL_COST_Q", "0.15")))
+                if new_trow is not None and len(new_trow) - 1 <= 1.4 * n_tiles:
+                    alt = build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows,
+                                          max_row_edges, candidates=(tr,), cluster=cluster,
+                                          trow_override=new_trow, equalize=False)
+                    if alt is not None and alt.pipe is not None:
+                        return alt
         return plan
     return None

@@ -1,23 +1,20 @@
-// Register-resident form of the two-phase row-group SpMM (reference call site:
-// lib/sgp_preprocessing.py:202, x = adj @ x).  gfx950 / wave64 only.  Same tiles, groups, column
-// classes, two-phase LDS-DMA staging and v_mfma_f32_4x4x1_16b_f32 arithmetic as spmm_pipe; what
-// differs is where a group's stream lives: the weights (one VGPR per 4 super-steps) and the
-// per-lane LDS address of every staged row it reads (one VGPR per super-step) are loaded ONCE per
-// workgroup into registers and stay there for the whole time chunk.  A super-step is then
-//         s_waitcnt lgkmcnt(n) | 4 x v_mfma_f32_4x4x1_16b_f32 | ds_read_b128 (D super-steps ahead)
-// with no VALU address arithmetic, no weight / offset reads from LDS and no read that depends on
-// another read -- on gfx950 every VALU instruction and every VGPR write of an LDS return takes
-// issue time from the fp32 matrix pipe (tools/ubench/res_loop2.hip: 42-46 cycles per 32 cycles of
-// MFMAs, fold and store included, against ~55 for the spmm_pipe body).
-// Registers hold the first SH super-steps of either range of a group (96 % of the ranges of the
-// 100-NN target graph are shorter); what lies beyond is walked from an LDS copy of the stream the
-// way spmm_pipe does (not software-pipelined: those groups mix rows of two distant clusters and
-// are the slowest of their tile in any case).
-//
-// The compiler is kept out of the inner loop's memory scheduling on purpose: hipcc sinks a plain LDS
-// load to its use across the scalar exit branches (read -> wait -> 4 MFMAs, serialised), so operand
-// reads and their waits are inline asm.  LDS operations return in order, which makes the wait
-// counts static (WAITN below).
+// Three-slot form of the register-resident two-phase row-group SpMM (reference call site:
+// lib/sgp_preprocessing.py:202, x = adj @ x).  gfx950 / wave64 only.  Arithmetic, groups, column
+// classes and the register-resident stream are those of spmm_res (bit-identical results for the
+// same plan); what differs is how far ahead the staging runs.  With two LDS regions a segment can
+// only be refilled while the other one is consumed: every LDS-DMA piece has ONE phase (~1.5 us) to
+// land, and a phase ends when its slowest piece has -- forcing 50 / 75 % of the staging reads to
+// hit the L2 buys 2 / 5 % (ablation bits 4 / 5 of spmm_res), forcing all of them 12 %: it is the
+// miss latency of the slowest piece, not the miss count, that is exposed.  Here the stage has
+// THREE slots of 192 rows: phase g computes on slot g mod 3 while the segment of phase g + 2 is
+// requested into slot (g + 2) mod 3 and the segment of phase g + 1 (requested one phase ago)
+// finishes landing, so every piece has two phases.  Slots are interleaved at DMA-piece (1 KiB)
+// granularity -- staged row j of a segment lives at 3072 (j / 4) + 1024 slot + 256 (j % 4) -- so
+// the slot enters an operand read as the IMMEDIATE offset of ds_read_b128 and the per-lane
+// addresses stay put in their registers; the time loop is unrolled by 3 steps (the slot pattern
+// repeats every 6 phases).  Price: 384 instead of 448 staged rows per tile (plan built for it,
+// graph.ShiftOperator.tri_plan) and no room for an LDS copy of the stream -- ranges beyond the
+// resident 20 super-steps read the plan arrays from global memory.
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,7 +28,7 @@ struct Src2 {
     int n_own;
 };
 
-struct ResArgs {
+struct TriArgs {
     const int* uptr; const int* ucol; const int* usplit;
     const int* gptr;                       // [2 * GT * n_tiles + 1]: (A, B) quad ranges per group
     const int* gsup;                       // [2 * GT * n_tiles]: super-steps per range
@@ -56,11 +53,10 @@ __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off)
 }
 
 // NW waves per workgroup, G row groups per wave (tile = 4 * NW * G rows), operand ring D super-steps
-// deep per group parity, PASSES x (4 NW) staged rows.  ABL: bit0 no staging DMA, bit2 staging
-// always reads the chunk's first step, bit4 / bit5 every staged row set is read for 2 / 4 consecutive
-// steps: 50 % / 75 % of the staging reads are forced L2 hits (ablation builds).
-template <bool HALO, int NW, int G, int D, int PASSES, int ABL = 0>
-__global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
+// deep per group parity, SEGP x (4 NW) staged rows per segment and slot.  ABL: bit0 no staging DMA,
+// bit2 staging always reads the chunk's first step (ablation builds).
+template <bool HALO, int NW, int G, int D, int SEGP, int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void spmm_tri(TriArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     constexpr int GT = NW * G;
     constexpr int RPP = NW * 4;                           // staged rows per DMA pass
@@ -89,78 +85,79 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
-    // ---- DMA bookkeeping: per-lane source offsets of the staged rows this lane feeds
-    unsigned voff[PASSES];
+    // ---- DMA bookkeeping: per-lane source offsets of the staged rows this lane feeds.  Pass p of
+    // segment s covers the segment's rows p RPP + 4 wave .. + 3 (piece p NW + wave).
+    unsigned voff[2][SEGP];
     unsigned halo_mask = 0;
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int u = p * RPP + eg;
-        const int c = (u < nU) ? a.ucol[u0 + u] : (nU > 0 ? a.ucol[u0] : 0);
-        if (HALO && c >= a.src.n_own) {
-            halo_mask |= 1u << p;
-            voff[p] = (unsigned)((c - a.src.n_own) * (int)a.src.xhrs + f_base + li * 4) * 4u;
-        } else {
-            voff[p] = (unsigned)(c * (int)a.src.xrs + f_base + li * 4) * 4u;
+    for (int sg = 0; sg < 2; ++sg) {
+        const int base = sg ? uA : 0, rows = sg ? nU - uA : uA;
+#pragma unroll
+        for (int p = 0; p < SEGP; ++p) {
+            const int u = p * RPP + eg;
+            const int c = (u < rows) ? a.ucol[u0 + base + u] : (nU > 0 ? a.ucol[u0] : 0);
+            if (HALO && c >= a.src.n_own) {
+                halo_mask |= 1u << (sg * SEGP + p);
+                voff[sg][p] = (unsigned)((c - a.src.n_own) * (int)a.src.xhrs + f_base + li * 4) * 4u;
+            } else {
+                voff[sg][p] = (unsigned)(c * (int)a.src.xrs + f_base + li * 4) * 4u;
+            }
         }
     }
     unsigned piecesA = 0, piecesB = 0;
+    int nA = 0, nB = 0;                                   // DMA instructions of this wave per segment
 #pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
+    for (int p = 0; p < SEGP; ++p) {
         const int r0 = p * RPP + wave * 4;
-        if (r0 < uA) piecesA |= 1u << p;
-        else if (r0 < nU) piecesB |= 1u << p;
+        if (r0 < uA) { piecesA |= 1u << p; ++nA; }
+        if (r0 < nU - uA) { piecesB |= 1u << p; ++nB; }
     }
     piecesA = __builtin_amdgcn_readfirstlane(piecesA);
     piecesB = __builtin_amdgcn_readfirstlane(piecesB);
-    const unsigned piece0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 1024u);
+    nA = __builtin_amdgcn_readfirstlane(nA);
+    nB = __builtin_amdgcn_readfirstlane(nB);
+    // piece (p, wave) of a segment in slot k: lds0 + 3072 (p NW + wave) + 1024 k
+    const unsigned piece0 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)wave * 3072u);
     const char* x_step = reinterpret_cast<const char*>(a.src.x + (long long)t_begin * a.src.xbs);
     const char* h_step = reinterpret_cast<const char*>(a.src.xh + (long long)t_begin * a.src.xhbs);
     const long long x_inc = a.src.xbs * 4, h_inc = a.src.xhbs * 4;
     const char* const x_step0 = x_step;
     const char* const h_step0 = h_step;
-    auto dma_segment = [&](const char* xt, const char* ht, unsigned pieces) {
+    auto dma_segment = [&](const char* xt, const char* ht, int sg, unsigned pieces, unsigned slot) {
         if constexpr (ABL & 1) return;
         if constexpr (ABL & 4) { xt = x_step0; ht = h_step0; }
-        if constexpr ((ABL & 48) != 0) {                  // every row set is staged for 2 (16) / 4 (32) steps in a row
-            const long long k = (xt - x_step0) / x_inc / ((ABL & 16) ? 2 : 4) * ((ABL & 16) ? 2 : 4);
-            xt = x_step0 + k * x_inc; ht = h_step0 + k * h_inc;
-        }
 #pragma unroll
-        for (int p = 0; p < PASSES; ++p) {
+        for (int p = 0; p < SEGP; ++p) {
             if (pieces & (1u << p)) {                     // scalar
-                const unsigned dst = piece0 + (unsigned)p * (unsigned)(RPP * 256);
+                const unsigned dst = piece0 + (unsigned)p * (unsigned)(NW * 3072) + slot * 1024u;
+                const unsigned vo = sg ? voff[1][p] : voff[0][p];
                 if constexpr (HALO) {
-                    const char* b = ((halo_mask >> p) & 1u) ? ht : xt;
-                    dma16_vaddr(b + voff[p], __builtin_amdgcn_readfirstlane(dst));
+                    const char* b = ((halo_mask >> (sg * SEGP + p)) & 1u) ? ht : xt;
+                    dma16_vaddr(b + vo, __builtin_amdgcn_readfirstlane(dst));
                 } else {
-                    dma16_saddr(voff[p], xt, dst);
+                    dma16_saddr(vo, xt, dst);
                 }
             }
         }
     };
-
-    // ---- the tile's stream -> LDS behind the stage (read only by ranges longer than SH)
-    constexpr int kStageBytes = PASSES * RPP * 256;
-    const int tile_q0 = a.gptr[tile * (2 * GT)], tile_q1 = a.gptr[tile * (2 * GT) + 2 * GT];
-    const int tile_quads = tile_q1 - tile_q0;
-    {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
-        f32x4* dst = reinterpret_cast<f32x4*>(lds + kStageBytes);
-        for (int i = tid; i < tile_quads * 16; i += NW * 64) dst[i] = src[i];
-        const f32x4* isrc = reinterpret_cast<const f32x4*>(a.gidx) + (long long)tile_q0 * 4;
-        f32x4* idst = reinterpret_cast<f32x4*>(lds + kStageBytes + tile_quads * 256);
-        for (int i = tid; i < tile_quads * 4; i += NW * 64) idst[i] = isrc[i];
-    }
+    // wait until at most `younger` of this wave's memory operations are outstanding: the pieces
+    // requested before them have landed (s_waitcnt takes an immediate)
+    auto wait_pieces = [&](int younger) {
+        if (younger <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else if (younger == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    };
+    static_assert(SEGP <= 3, "wait_pieces covers up to 3 pieces per segment and wave");
 
     // ---- the wave's stream -> registers (once per workgroup)
     // weights: lane (q, b = li >> 2, i = li & 3) holds row i's weight for class q's column in
-    // super-step 4 p + b (gw is stored one float per lane and quad: the MFMA of super-step s takes
-    // block s & 3 of its class, cbsz = 2 / abid); addresses: lane (q, li) holds the LDS byte address
-    // of chunk li of class q's staged row in super-step s.  Padding reads row 0 with weight 0.
+    // super-step 4 p + b; addresses: lane (q, li) holds the slot-0 LDS byte address of chunk li of
+    // class q's staged row in super-step s.  Padding reads staged row 0 with weight 0.
     unsigned addr[2][G][SH];
     float w[2][G][WH];
     int n[2][G];
-    int qrel[2][G];                                        // first quad of the range, relative to the tile
+    int q0s[2][G];                                         // first quad of the range (global)
     unsigned yoff[G];
     bool has_row[G];
 #pragma unroll
@@ -173,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         for (int ph = 0; ph < 2; ++ph) {
             const int qb = ph ? q1 : q0, qe = ph ? q2 : q1;
             n[ph][g] = __builtin_amdgcn_readfirstlane(a.gsup[grp + ph]);
-            qrel[ph][g] = qb - tile_q0;
+            q0s[ph][g] = qb;
 #pragma unroll
             for (int p = 0; p < WH; ++p)
                 w[ph][g][p] = (qb + p < qe) ? a.gw[(long long)(qb + p) * 64 + lane] : 0.f;
@@ -222,19 +219,16 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         if (has_row[g]) __builtin_nontemporal_store(out, reinterpret_cast<f32x4*>(ys + yoff[g]));
     };
 
-    // super-steps SH .. n-1 of a long range, from the LDS copy of the stream (whole quads: the
-    // padding of the last one has weight 0)
+    // super-steps SH .. n-1 of a long range, from the plan arrays in global memory (whole quads:
+    // the padding of the last one has weight 0 / staged row 0)
     typedef const __attribute__((address_space(3))) f32x4* lds_f4_t;
-    typedef const __attribute__((address_space(3))) float* lds_f1_t;
-    typedef const __attribute__((address_space(3))) unsigned* lds_u1_t;
-    auto overflow = [&](int g, int qr, int nsteps) {
-        const unsigned wl = lds0 + kStageBytes + (unsigned)qr * 256u + lane * 4;
-        const unsigned il = lds0 + kStageBytes + (unsigned)tile_quads * 256u + (unsigned)qr * 64u + q * 16;
+    auto overflow = [&](int g, int qfirst, int nsteps, unsigned slot_off) {
         for (int c = WH; c < ((nsteps + 3) >> 2); ++c) {
-            const float wv = *(lds_f1_t)(wl + c * 256);
+            const float wv = a.gw[(long long)(qfirst + c) * 64 + lane];
             f32x4 xs[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) xs[b] = *(lds_f4_t)(lds0 + *(lds_u1_t)(il + c * 64 + b * 4) + li * 16);
+            for (int b = 0; b < 4; ++b)
+                xs[b] = *(lds_f4_t)(lds0 + (unsigned)a.gidx[(long long)(qfirst + c) * 16 + q * 4 + b] + slot_off + li * 16);
             acc[g][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xs[0].x, acc[g][0], 2, 0, 0);
             acc[g][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xs[0].y, acc[g][1], 2, 0, 0);
             acc[g][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(wv, xs[0].z, acc[g][2], 2, 0, 0);
@@ -254,11 +248,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         }
     };
 
-#define SGP_RD(P_, G_, S_) asm volatile("ds_read_b128 %0, %1" : "=v"(ring[(G_) & 1][(S_) % D]) : "v"(addr[P_][G_][S_]))
-    // LDS reads issued after r(g, s) when super-step (g, s) starts: its ring refills (s >= D), or,
-    // for the D super-steps requested ahead, the rest of that request + the look-ahead request of
-    // group g + 1 + the refills of super-steps 0 .. s-1 (the previous group's refills in between
-    // only make the count conservative)
+    // K_ = slot of the segment (compile-time): it enters the read as the immediate offset
+#define SGP_RD(P_, G_, S_, K_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ring[(G_) & 1][(S_) % D]) : "v"(addr[P_][G_][S_]), "n"((K_) * 1024))
 #define SGP_WAITN(G_, S_) ((S_) >= D ? ((SH - 1 - (S_)) < (D - 1) ? (SH - 1 - (S_)) : (D - 1)) : (D - 1 + ((G_) + 1 < G ? D : 0)))
 #define SGP_WT(G_, S_) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[(G_) & 1][(S_) % D]) : "n"(SGP_WAITN(G_, S_)))
 #define SGP_MF(ACC_, W_, X_, AB_) __builtin_amdgcn_mfma_f32_4x4x1f32(W_, X_, ACC_, 2, AB_, 0)
@@ -278,56 +269,62 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 #define SGP_SLOT(P_, G_, S_, FIRST_)                                                               \
     if (((S_) & 3) == 0) SGP_SLOT4(P_, G_, S_, 0, FIRST_) else if (((S_) & 3) == 1) SGP_SLOT4(P_, G_, S_, 1, FIRST_) \
     else if (((S_) & 3) == 2) SGP_SLOT4(P_, G_, S_, 2, FIRST_) else SGP_SLOT4(P_, G_, S_, 3, FIRST_)
-    // One phase = region P_ of the stage.  The first D super-steps of group g + 1 are requested at
-    // the start of group g (other ring parity), so only a phase's first group starts cold, and that
-    // wait is covered by the fold + store of the previous step (MID_).  In phase A a group with
-    // columns restarts its accumulators through the first MFMAs (C = 0); one without is cleared.
-#define SGP_PHASE(P_, MID_)                                                                        \
-    { _Pragma("unroll") for (int s = 0; s < D; ++s) SGP_RD(P_, 0, s); }                            \
+#define SGP_PHASE(P_, K_, MID_)                                                                    \
+    { _Pragma("unroll") for (int s = 0; s < D; ++s) SGP_RD(P_, 0, s, K_); }                        \
     _Pragma("unroll") for (int g = 0; g < G; ++g) {                                                \
-        if (g + 1 < G) { _Pragma("unroll") for (int s = 0; s < D; ++s) SGP_RD(P_, g + 1, s); }     \
+        if (g + 1 < G) { _Pragma("unroll") for (int s = 0; s < D; ++s) SGP_RD(P_, g + 1, s, K_); } \
         if (g == 0) { MID_ }                                                                       \
         if ((P_) == 1 && g > 0) emit(g - 1, y_step);                                               \
         if (n[P_][g] > 0) {                                                                        \
             _Pragma("unroll") for (int s = 0; s < SH; ++s) {                                       \
                 SGP_WT(g, s);                                                                      \
                 SGP_SLOT(P_, g, s, (P_) == 0 && s == 0)                                            \
-                if (s + D < SH) SGP_RD(P_, g, s + D);                                              \
+                if (s + D < SH) SGP_RD(P_, g, s + D, K_);                                          \
                 if (s + 1 == n[P_][g]) break;                                                      \
             }                                                                                      \
-            if (n[P_][g] > SH) overflow(g, qrel[P_][g], n[P_][g]);                                 \
+            if (n[P_][g] > SH) overflow(g, q0s[P_][g], n[P_][g], (K_) * 1024u);                    \
         } else if ((P_) == 0) {                                                                    \
             acc[g][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[g][1] = acc[g][0]; acc[g][2] = acc[g][0]; acc[g][3] = acc[g][0]; \
         }                                                                                          \
     }
+    // One step with compile-time slots: segment A of the step sits in slot KA_, B in KB_; the
+    // segments of the NEXT step are requested into the two slots that become free, two phases
+    // before they are consumed.
+#define SGP_STEP(KA_, KB_, KNA_, KNB_)                                                             \
+    {                                                                                              \
+        const bool more = t + 1 < t_end;                                                           \
+        _Pragma("unroll") for (int g = 0; g < G; ++g) asm volatile("" : "+s"(n[0][g]), "+s"(n[1][g])); \
+        asm volatile("s_barrier" ::: "memory");            /* A(t) landed, slot KNA_ consumed */   \
+        if (dma_first && more) dma_segment(x_step + x_inc, h_step + h_inc, 0, piecesA, KNA_);      \
+        SGP_PHASE(0, KA_, if (t > t_begin) emit(G - 1, y_step - y_inc);)                           \
+        if (!dma_first && more) dma_segment(x_step + x_inc, h_step + h_inc, 0, piecesA, KNA_);     \
+        wait_pieces(more ? nA : 0);                         /* this wave's pieces of B(t) */        \
+        asm volatile("s_barrier" ::: "memory");                                                    \
+        if (dma_first && more) dma_segment(x_step + x_inc, h_step + h_inc, 1, piecesB, KNB_);      \
+        SGP_PHASE(1, KB_, )                                                                        \
+        if (!dma_first && more) dma_segment(x_step + x_inc, h_step + h_inc, 1, piecesB, KNB_);     \
+        wait_pieces(more ? nB : 0);                         /* this wave's pieces of A(t+1) */      \
+        x_step += x_inc; h_step += h_inc; y_step += y_inc;                                         \
+        ++t;                                                                                       \
+    }
 
     __syncthreads();
-    dma_segment(x_step, h_step, piecesA);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dma_segment(x_step, h_step, 0, piecesA, 0);
+    dma_segment(x_step, h_step, 1, piecesB, 1);
+    wait_pieces(nB);                                       // A(t_begin) landed, B may still fly
     const bool dma_first = wave >= NW / 2;
-    for (int t = t_begin; t < t_end; ++t) {
-        // the range lengths are re-made opaque every step: otherwise hipcc hoists all exit
-        // comparisons out of the time loop as 64-bit masks and spills them to VGPR lanes
-#pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" : "+s"(n[0][g]), "+s"(n[1][g]));
-        // ---- phase A: region A holds step t once every wave's pieces have landed
-        asm volatile("s_barrier" ::: "memory");
-        // the refill of the other region is issued first by the younger half of the waves (they
-        // would wait for the matrix pipe anyway) and after their super-steps by the older half
-        if (dma_first) dma_segment(x_step, h_step, piecesB);
-        SGP_PHASE(0, if (t > t_begin) emit(G - 1, y_step - y_inc);)
-        if (!dma_first) dma_segment(x_step, h_step, piecesB);
-        // ---- phase B
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
-        SGP_PHASE(1, )
-        if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
-        // this wave's pieces of A(t+1) (and its stores) retired before the barrier
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        x_step += x_inc; h_step += h_inc; y_step += y_inc;
+    int t = t_begin;
+    while (t < t_end) {
+        // the piece masks are re-made opaque every round (hoisted branch masks would be spilled)
+        asm volatile("" : "+s"(piecesA), "+s"(piecesB), "+s"(nA), "+s"(nB));
+        SGP_STEP(0, 1, 2, 0)                               // phases 6k, 6k+1: slots 0, 1; next -> 2, 0
+        if (t >= t_end) break;
+        SGP_STEP(2, 0, 1, 2)                               // phases 6k+2, 6k+3
+        if (t >= t_end) break;
+        SGP_STEP(1, 2, 0, 1)                               // phases 6k+4, 6k+5
     }
     emit(G - 1, y_step - y_inc);
+#undef SGP_STEP
 #undef SGP_PHASE
 #undef SGP_SLOT
 #undef SGP_SLOT4
@@ -337,51 +334,52 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 #undef SGP_RD
 }
 
-int g_res_cfg = -1;
-int res_cfg() {                                            // 0: 16 waves x 1 group, 1: 8 waves x 2 groups
-    if (g_res_cfg < 0) { const char* e = getenv("SGP_SPMM_RES_CFG"); g_res_cfg = e ? atoi(e) : 0; }
-    return g_res_cfg;
+int g_tri_cfg = -1;
+int tri_cfg() {                                            // 0: 16 waves x 1 group, 1: 8 waves x 2 groups
+    if (g_tri_cfg < 0) { const char* e = getenv("SGP_SPMM_TRI_CFG"); g_tri_cfg = e ? atoi(e) : 0; }
+    return g_tri_cfg;
 }
-int res_chunk_cap() {
+int tri_chunk_cap() {
     static int v = -1;
     if (v < 0) { const char* e = getenv("SGP_SPMM_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }
     return v;
 }
 
-template <bool HALO, int NW, int G, int D, int PASSES>
-int launch_res(const ResArgs& a, hipStream_t s) {
-    const size_t lds_bytes = 160 * 1024;
+template <bool HALO, int NW, int G, int D, int SEGP>
+int launch_tri(const TriArgs& a, hipStream_t s) {
+    const size_t lds_bytes = 3 * SEGP * NW * 4 * 256;    // three slots
     dim3 grid((unsigned)(a.n_tiles * a.n_tchunks), a.feat / 64);
 #ifdef SGP_ABLATION
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
 #define SGP_ABL(V)                                                                                 \
     if (abl == V) {                                                                                \
-        auto k4 = spmm_res<HALO, NW, G, D, PASSES, V>;                                             \
+        auto k4 = spmm_tri<HALO, NW, G, D, SEGP, V>;                                             \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
-        return sgp::check_launch("spmm_res");                                                      \
+        return sgp::check_launch("spmm_tri");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32)
+    SGP_ABL(1) SGP_ABL(4)
 #undef SGP_ABL
 #endif
-    auto kern = spmm_res<HALO, NW, G, D, PASSES>;
+    auto kern = spmm_tri<HALO, NW, G, D, SEGP>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "spmm_res: LDS opt-in: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds_bytes, s, a);
-    return sgp::check_launch("spmm_res");
+    return sgp::check_launch("spmm_tri");
 }
 
 }  // namespace
 
 extern "C" {
 
-int32_t sgp_spmm_res_max_union(void) { return 7 * 64; }
-int32_t sgp_spmm_res_max_quads(void) { return (160 * 1024 - 7 * 64 * 256) / (256 + 64); }
-int sgp_spmm_res_tune(int32_t cfg) { if (cfg >= 0) g_res_cfg = cfg; return 0; }
+// two segments of at most 3 x 64 = 192 rows; the parity cut pads segment A to 4 rows
+int32_t sgp_spmm_tri_max_union(void) { return 2 * 192 - 4; }
+int32_t sgp_spmm_tri_max_quads(void) { return 1 << 20; }   // the stream is never copied to LDS
+int sgp_spmm_tri_tune(int32_t cfg) { if (cfg >= 0) g_tri_cfg = cfg; return 0; }
 
-int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+int sgp_spmm_tri_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
                      const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
                      const int32_t* rowmap,
                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
@@ -391,25 +389,26 @@ int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                      sgp_stream_t stream) {
     SGP_REQUIRE(uptr && ucol && usplit && gptr && gsup && gidx && gw && rowmap && X && Y,
-                "sgp_spmm_res_f32: null pointer");
+                "sgp_spmm_tri_f32: null pointer");
     SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,
-                "sgp_spmm_res_f32: bad size");
+                "sgp_spmm_tri_f32: bad size");
     {
         const long long own = Xh ? n_own : n_cols, far = Xh ? n_cols - n_own : 0;
         SGP_REQUIRE(n_cols >= 0 && own >= 0 && far >= 0 && own * xrs < (1ll << 30) && far * xhrs < (1ll << 30) &&
                     (long long)n_rows * yrs < (1ll << 30),
-                    "sgp_spmm_res_f32: row offsets exceed 32 bits (use sgp_spmm_csr_f32)");
+                    "sgp_spmm_tri_f32: row offsets exceed 32 bits (use sgp_spmm_csr_f32)");
     }
     if (n_rows == 0 || batch == 0 || feat == 0) return 0;
     if (feat % 64 != 0)
-        return sgp::fail(SGP_EUNSUP, "sgp_spmm_res_f32: feat=%d is not a multiple of 64", feat);
-    if (max_union > sgp_spmm_res_max_union() || max_tile_quads > sgp_spmm_res_max_quads())
-        return sgp::fail(SGP_EUNSUP, "sgp_spmm_res_f32: tile working set (%d rows, %d quads) exceeds LDS (%d, %d)",
-                         max_union, max_tile_quads, sgp_spmm_res_max_union(), sgp_spmm_res_max_quads());
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_tri_f32: feat=%d is not a multiple of 64", feat);
+    // (max_union counts the padding of segment A: 380 distinct rows stage as at most 192 + 190)
+    if (max_union > 2 * 192 || max_tile_quads > sgp_spmm_tri_max_quads())
+        return sgp::fail(SGP_EUNSUP, "sgp_spmm_tri_f32: tile working set (%d rows, %d quads) exceeds LDS (%d, %d)",
+                         max_union, max_tile_quads, sgp_spmm_tri_max_union(), sgp_spmm_tri_max_quads());
     SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && yrs % 4 == 0 && ybs % 4 == 0 && sgp::aligned16(X) &&
                 sgp::aligned16(Y) && (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh))),
-                "sgp_spmm_res_f32: strides/pointers must be 16-byte aligned");
-    ResArgs a;
+                "sgp_spmm_tri_f32: strides/pointers must be 16-byte aligned");
+    TriArgs a;
     a.uptr = uptr; a.ucol = ucol; a.usplit = usplit; a.gptr = gptr; a.gsup = gsup; a.gidx = gidx; a.gw = gw;
     a.rowmap = rowmap;
     a.n_tiles = n_tiles;
@@ -418,14 +417,12 @@ int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
     a.n_rows = n_rows; a.batch = batch; a.feat = feat;
     const int nft = feat / 64;
     long long want = (long long)batch * n_tiles * nft / 4096;
-    int tc = (int)(want < 16 ? 16 : (want > res_chunk_cap() ? res_chunk_cap() : want));
+    int tc = (int)(want < 16 ? 16 : (want > tri_chunk_cap() ? tri_chunk_cap() : want));
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
     hipStream_t s = (hipStream_t)stream;
-    if (res_cfg() == 1)
-        return Xh ? launch_res<true, 8, 2, 4, 14>(a, s) : launch_res<false, 8, 2, 4, 14>(a, s);
-    return Xh ? launch_res<true, 16, 1, 4, 7>(a, s) : launch_res<false, 16, 1, 4, 7>(a, s);
+    return Xh ? launch_tri<true, 16, 1, 4, 3>(a, s) : launch_tri<false, 16, 1, 4, 3>(a, s);
 }
 
 }  // extern "C"

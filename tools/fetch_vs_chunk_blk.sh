@@ -5,7 +5,7 @@ ROOTD=$PWD
 for c in ${CHUNKS:-4 8 16 32}; do
   export SGP_SPMM_CHUNK=$c
   echo "chunk $c: $(python $ROOTD/tools/probe_blk.py 2>&1 | grep 'cfg=')"
-  (cd /tmp && rocprofv3 --output-format csv --pmc FETCH_SIZE TCC_HIT_sum TCC_MISS_sum -d /tmp/fvc_$c -o p -- python $ROOTD/tools/probe_blk.py > /tmp/fvc_$c.log 2>&1)
+  (cd /tmp && rocprofv3 --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d /tmp/fvc_$c -o p -- python $ROOTD/tools/probe_blk.py > /tmp/fvc_$c.log 2>&1)
   python - <<PY
 import csv,glob,collections
 acc=collections.defaultdict(float); n=collections.defaultdict(int)

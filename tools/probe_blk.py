@@ -25,14 +25,23 @@ def main():
     y = torch.empty_like(x)
     y0 = torch.empty_like(x)
     bytes_hop = 2 * N * T * D * 4 + op.nnz() * 8 + (N + 1) * 4
-    bp = op.block_plan(D, x.device)
-    print("blk tiles", bp.n_tiles, "max_union", bp.max_union, "max_steps", bp.max_steps, "fill", round(bp.fill, 4), flush=True)
+    kernels = os.environ.get("SGP_PROBE_KERNELS", "res,blk").split(",")
+    if "blk" in kernels:
+        bp = op.block_plan(D, x.device)
+        print("blk tiles", bp.n_tiles, "max_union", bp.max_union, "max_steps", bp.max_steps, "fill", round(bp.fill, 4), flush=True)
+    else:
+        tp = op.tile_plan(D, x.device)
+        print("tiles", tp.n_tiles, "fill", round(tp.pipe["fill"], 4), flush=True)
+        if "tri" in kernels:
+            tt = op.tri_plan(D, x.device)
+            print("tri tiles", tt.n_tiles, "fill", round(tt.pipe["fill"], 4), "max_union", tt.pipe["max_union"], flush=True)
     if os.environ.get("SGP_PROBE_CHECK", "1") == "1":
         op.propagate(x[:4], y0[:4], force="csr")
-        op.propagate(x[:4], y[:4], force="blk")
-        err = (y[:4] - y0[:4]).abs().max().item()
-        print(f"blk vs csr: max|diff| = {err:.3g}  allclose(1e-5) = {torch.allclose(y[:4], y0[:4], rtol=1e-5, atol=1e-5)}", flush=True)
-    for force in os.environ.get("SGP_PROBE_KERNELS", "res,blk").split(","):
+        for kname in kernels:
+            op.propagate(x[:4], y[:4], force=kname)
+            err = (y[:4] - y0[:4]).abs().max().item()
+            print(f"{kname} vs csr: max|diff| = {err:.3g}  allclose(1e-5) = {torch.allclose(y[:4], y0[:4], rtol=1e-5, atol=1e-5)}", flush=True)
+    for force in kernels:
         for cfg in ([0] if force != "blk" else [int(c) for c in os.environ.get("SGP_PROBE_CFGS", "0,1,2").split(",")]):
             hip.load().sgp_spmm_blk_tune(cfg)
             ms = timeit(lambda: op.propagate(x, y, force=force))

@@ -60,3 +60,49 @@ def test_no_cpu_fallback():
         enc(torch.zeros(2, 3, 3))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sgp_amd.sgp_spatial_embedding(torch.zeros(2, 3, 4), 3, torch.tensor([[0, 1], [1, 2]]))
+
+
+ASAN_LIB = os.path.join(ROOT, "sgp_amd", "csrc", "build_asan", "libsgp_amd_asan.so")
+
+
+def test_host_asan_build():
+    """the host halves of the library under AddressSanitizer (`make -C sgp_amd/csrc
+    asan`; GPU ASan is not available on this pool).  Every entry point is driven through its
+    argument checks -- null pointers, zero and negative sizes, unsupported shapes -- in a child
+    process that preloads the ASan runtime; an ASan report aborts the child."""
+    import glob
+    import subprocess
+    import sys
+    if not os.path.exists(ASAN_LIB):
+        pytest.skip("build it with `make -C sgp_amd/csrc asan` (about a minute)")
+    rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
+    if not rt:
+        pytest.skip("no ASan runtime in this image")
+    child = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+from sgp_amd import hip
+lib = ctypes.CDLL(%r)
+n_calls = 0
+for name, (restype, argtypes) in hip.SIGNATURES.items():
+    fn = getattr(lib, name)
+    fn.restype, fn.argtypes = restype, argtypes
+    if restype is not ctypes.c_int:
+        continue                                   # size queries are exercised below
+    for fill in (0, -1, 3):
+        scalar = lambda a: isinstance(a, type) and issubclass(a, ctypes._SimpleCData) and \
+            a not in (ctypes.c_void_p, ctypes.c_char_p)
+        args = [a(fill) if scalar(a) else None for a in argtypes]
+        rc = fn(*args)
+        assert isinstance(rc, int)
+        n_calls += 1
+lib.sgp_last_error.restype = ctypes.c_char_p
+assert isinstance(lib.sgp_last_error(), bytes)
+for f, r, l in ((3, 16, 8), (64, 64, 2), (300, 64, 2), (3, 16, 40)):
+    lib.sgp_reservoir_fused_supported(f, r, l); lib.sgp_reservoir_fused_workspace_bytes(f, r, l)
+    lib.sgp_reservoir_workspace_bytes(f, r); lib.sgp_gesn_workspace_bytes(100, r, l)
+print("asan-ok", n_calls)
+''' % (ROOT, ASAN_LIB)
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    res = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "asan-ok" in res.stdout, (res.stdout[-500:], res.stderr[-3000:])

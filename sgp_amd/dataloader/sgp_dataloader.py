@@ -12,13 +12,23 @@ apply the explicit supports of ``sgp_spatial_support`` to every sample,
 ``apply_supports`` is that expression with the products on the MI355X (``sgp_spmm_csr_f32`` on
 the supports' CSR, rectangular for a node subset) and every block written straight into its slot
 of the result (no ``torch.cat``).  The supports come from ``sgp_amd.sgp_spatial_support`` (the
-reference's quirks included); a dense support (``global_attr``'s 1/N matrix) is a plain matmul.
+reference's quirks included); the dense support of ``global_attr`` (1/N everywhere) is the scaled
+column sum of x broadcast to every row (``sgp_node_sums`` + ``sgp_bcast_rows``).
 The DataLoader / Batch plumbing around these lines is tsl's and is not rebuilt here.
 """
 import torch
 
 from .. import hip
 from ..graph import ShiftOperator
+
+
+def _rect_dense(a, x3, dst):
+    """Rows of a dense support selected by ``node_index``: CSR of the [rows, N] block."""
+    r, c = a.nonzero(as_tuple=True)
+    counts = torch.bincount(r, minlength=a.shape[0])
+    rowptr = torch.zeros(a.shape[0] + 1, dtype=torch.long)
+    rowptr[1:] = torch.cumsum(counts, 0)
+    ShiftOperator(rowptr, c, a[r, c], a.shape[0], num_cols=a.shape[1]).propagate_rect(x3, dst)
 
 
 def apply_supports(x, support, node_index=None):
@@ -45,9 +55,17 @@ def apply_supports(x, support, node_index=None):
         if isinstance(adj, ShiftOperator):
             op = adj if idx is None else adj.index_select(0, idx)
             op.propagate_rect(x3, dst)
-        else:                                        # dense support (global_attr: 1/N everywhere)
-            a = torch.as_tensor(adj, dtype=torch.float32).to(xg.device)
-            a = a if idx is None else a[idx.to(xg.device)]
-            dst.copy_(torch.matmul(a, x3))
+        else:
+            # dense support.  The reference has exactly one (global_attr: 1/N everywhere,
+            # sgp_preprocessing.py:157-158): a constant matrix times x is the scaled column sum of
+            # x in every row -- sgp_node_sums / sgp_bcast_rows, no N x N product.  Any other dense
+            # matrix goes through the CSR kernel like the sparse supports.
+            a = torch.as_tensor(adj, dtype=torch.float32).cpu()
+            a = a if idx is None else a[idx]
+            c = float(a.flatten()[0]) if a.numel() else 0.0
+            if a.numel() and bool((a == c).all()):
+                hip.bcast_rows(hip.node_sums(x3), c, dst)
+            else:
+                _rect_dense(a, x3, dst)
     out = out.reshape(*lead, rows, out.shape[-1])
     return out if dev_in == out.device else out.to(dev_in)

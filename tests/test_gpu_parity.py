@@ -1069,3 +1069,22 @@ def test_spmm_csr_scalar_path_long_batch():
     close(y[-3:], dense_ref(op, x[-3:]))
     close(y[65534:65537], dense_ref(op, x[65534:65537]))
     assert torch.isfinite(y).all()
+
+
+def test_apply_supports_dense_matrices_without_matmul():
+    """A dense support is either the constant 1/N matrix of global_attr (scaled column sums) or an
+    arbitrary matrix (CSR kernel on its non-zeros); also for a node subset."""
+    from sgp_amd.dataloader import apply_supports
+    torch.manual_seed(15)
+    n, f = 37, 5
+    x = torch.randn(3, n, f)
+    dense = torch.randn(n, n) * (torch.rand(n, n) < 0.3)
+    const = torch.full((n, n), 1.0 / n)
+    idx = torch.tensor([4, 0, 36, 4])
+    got = apply_supports(x.cuda(), [const, dense])
+    close(got[..., f:2 * f], const @ x)
+    close(got[..., 2 * f:], dense @ x)
+    sub = apply_supports(x.cuda(), [const, dense], idx)
+    close(sub[..., :f], x[:, idx])
+    close(sub[..., f:2 * f], (const @ x)[:, idx])
+    close(sub[..., 2 * f:], (dense @ x)[:, idx])

@@ -414,6 +414,32 @@ def test_gesn_against_oracle(n, f, r, L, act):
     close(y, ref, rtol=tol, atol=tol, fro=1e-5)
 
 
+def test_gesn_long_sequence():
+    """T = 301 spans two chunks of the layer-0 input GEMM (256 steps each) and an odd number of
+    ping-pong swaps of the state buffers; it must equal the same sequence run in short pieces
+    (state carried by the caller) bit for bit, and match the oracle."""
+    torch.manual_seed(17)
+    n, f, r, L, t = 60, 2, 40, 2, 301
+    ei, ew = synthetic.sparse_traffic_graph(n, 400, seed=3)
+    enc = sgp_amd.GESNEncoder(f, r, L, .9, .9, .7, 1., True)
+    x = torch.randn(t, n, f)
+    y = enc(x, ei, ew)
+    from sgp_amd.nn.encoders.dyn_gesn_encoder import gesn_operator
+    op = gesn_operator(ei, ew, n)
+    pieces, h = [], None
+    for t0 in range(0, t, 50):
+        o, h = enc.reservoir(x[None, t0:t0 + 50], op, h=None if h is None else list(h))
+        pieces.append(o[0])
+    assert torch.equal(torch.cat(pieces).cpu(), y.cpu())
+    layers = [dict(w_ih=l.w_ih.data, w_hh=l.w_hh.data, b_ih=l.b_ih.data, alpha=float(l.alpha))
+              for l in enc.reservoir.rnn_cells]
+    ref = O.gesn_forward(x, ei, ew, layers)
+    ref64 = O.gesn_forward(x, ei, ew, layers, dtype=torch.float64)
+    e_gpu = float((y.double().cpu() - ref64).abs().max())
+    e_cpu = float((ref.double() - ref64).abs().max())
+    assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
+
+
 def test_graph_esn_module_and_layer_step():
     torch.manual_seed(9)
     n, f, r = 40, 3, 48

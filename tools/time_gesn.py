@@ -1,5 +1,6 @@
 """Time the DynGESN baseline encoder on the shipped METR-LA shape (config/traffic/gesn.yaml)."""
-import sys, time
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import sgp_amd
 from sgp_amd import synthetic

@@ -204,6 +204,32 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
         for (int p = 0; p < PFD - 1; ++p) dma_x(p);
     }
 
+    // narrow layers keep their weight fragments in registers for the whole sequence (the barrier's
+    // memory clobber keeps the compiler from hoisting the LDS reads itself: three dependent
+    // ds_read + wait rounds per step otherwise); wide ones (JT = 4: 128 VGPRs of weights) read
+    // them from LDS every step
+    constexpr bool WREG = JT <= 2;
+    f32x4 rb[JT], rwh[JT][JT], rwx[JT][JT];
+    float rw0[JT][NKX];
+    if constexpr (WREG) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            rb[jt] = *reinterpret_cast<const f32x4*>(bias + jt * 16 + q * 4);
+#pragma unroll
+            for (int kb = 0; kb < JT; ++kb) {
+                rwh[jt][kb] = *reinterpret_cast<const f32x4*>(wh + ((jt * JT + kb) * 64 + lane) * 4);
+                rwx[jt][kb] = *reinterpret_cast<const f32x4*>(wx + ((jt * JT + kb) * 64 + lane) * 4);
+            }
+#pragma unroll
+            for (int ks = 0; ks < NKX; ++ks) {
+                if constexpr (NKX % 4 == 0)
+                    rw0[jt][ks] = wx[((jt * (NKX / 4) + ks / 4) * 64 + lane) * 4 + (ks & 3)];
+                else
+                    rw0[jt][ks] = wx[(jt * NKX + ks) * 64 + lane];
+            }
+        }
+    }
+
     const int n_iter = a.T + L - 1;
     for (int i = 0; i < n_iter; ++i) {
         const int t = i - l;
@@ -230,15 +256,19 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
             }
             f32x4 acc[JT];
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt)
-                acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+            for (int jt = 0; jt < JT; ++jt) {
+                if constexpr (WREG) acc[jt] = rb[jt];
+                else acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+            }
             // recurrent part first: its operands are this wave's registers
 #pragma unroll
             for (int kb = 0; kb < JT; ++kb) {
                 f32x4 wf[JT];
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt)
-                    wf[jt] = *reinterpret_cast<const f32x4*>(wh_t + ((jt * JT + kb) * 64 + lane) * 4);
+                for (int jt = 0; jt < JT; ++jt) {
+                    if constexpr (WREG) wf[jt] = rwh[jt][kb];
+                    else wf[jt] = *reinterpret_cast<const f32x4*>(wh_t + ((jt * JT + kb) * 64 + lane) * 4);
+                }
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -252,8 +282,10 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                 for (int kb = 0; kb < JT; ++kb) {
                     f32x4 wf[JT];
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-                        wf[jt] = *reinterpret_cast<const f32x4*>(wx_t + ((jt * JT + kb) * 64 + lane) * 4);
+                    for (int jt = 0; jt < JT; ++jt) {
+                        if constexpr (WREG) wf[jt] = rwx[jt][kb];
+                        else wf[jt] = *reinterpret_cast<const f32x4*>(wx_t + ((jt * JT + kb) * 64 + lane) * 4);
+                    }
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -265,7 +297,9 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                 for (int k4 = 0; k4 < NKX / 4; ++k4)
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt) {
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wx_t + ((jt * (NKX / 4) + k4) * 64 + lane) * 4);
+                        f32x4 wv;
+                        if constexpr (WREG) wv = f32x4{rw0[jt][4 * k4], rw0[jt][4 * k4 + 1], rw0[jt][4 * k4 + 2], rw0[jt][4 * k4 + 3]};
+                        else wv = *reinterpret_cast<const f32x4*>(wx_t + ((jt * (NKX / 4) + k4) * 64 + lane) * 4);
 #pragma unroll
                         for (int s = 0; s < 4; ++s)
                             acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], x_ok[4 * k4 + s] ? xrow[(4 * k4 + s) * 64 + lane] : 0.f, acc[jt], 0, 0, 0);
@@ -275,7 +309,7 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                 for (int ks = 0; ks < NKX; ++ks)
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt)
-                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[(jt * NKX + ks) * 64 + lane],
+                        acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(WREG ? rw0[jt][ks] : wx_t[(jt * NKX + ks) * 64 + lane],
                                                                        x_ok[ks] ? xrow[ks * 64 + lane] : 0.f, acc[jt], 0, 0, 0);
             }
             if (a.act == SGP_ACT_TANH) {

@@ -109,10 +109,16 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
         return time.time() - t0
 
     results = {}
-    for threads in settings:
+    for threads in sorted(settings):              # the 32-thread figure first
         torch.set_num_threads(threads)
         run(1)                                    # warm-up (thread pool)
         probe = run(2) / 2                        # seconds per step
+        best_so_far = max((v[0] for v in results.values()), default=0.0)
+        if best_so_far and n / probe < 0.5 * best_so_far:
+            # (all 256 hardware threads: the oracle's small per-step ops drown in dispatch --
+            # keep the probe's figure instead of spending half a minute on best-of-3)
+            results[threads] = (n / probe, 2)
+            continue
         per_run = seconds_budget / len(settings) / 3.5
         t = int(max(2, min(w["T"], per_run / max(probe, 1e-6))))
         best = min(run(t) for _ in range(3))

@@ -41,6 +41,7 @@ struct ResArgs {
     float* Y; long long yrs, ybs;
     int n_rows, batch, feat;
     int t_chunk, n_tchunks;
+    unsigned* dbg;                         // timeline stamps (ablation builds only)
 };
 
 constexpr int SH = 20;                     // super-steps per range held in registers (80 columns)
@@ -58,7 +59,8 @@ __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off)
 // NW waves per workgroup, G row groups per wave (tile = 4 * NW * G rows), operand ring D super-steps
 // deep per group parity, PASSES x (4 NW) staged rows.  ABL: bit0 no staging DMA, bit2 staging
 // always reads the chunk's first step, bit4 / bit5 every staged row set is read for 2 / 4 consecutive
-// steps: 50 % / 75 % of the staging reads are forced L2 hits (ablation builds).
+// steps: 50 % / 75 % of the staging reads are forced L2 hits, bit7 per-wave s_memtime timeline of one
+// workgroup (tools/timeline_res.py) (ablation builds).
 template <bool HALO, int NW, int G, int D, int PASSES, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -301,6 +303,17 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         }                                                                                          \
     }
 
+    // debug timeline (ABL & 128): workgroup 777 records s_memtime at 10 points of 4 steps
+    auto stamp = [&](int t, int point) {
+        if constexpr ((ABL & 128) != 0) {
+            const int ts = t - t_begin - 8;
+            if (wg == 777 && ts >= 0 && ts < 4) {
+                const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();
+                if (lane == 0) a.dbg[((ts * NW + wave) * 10 + point)] = now;
+            }
+        }
+    };
+
     __syncthreads();
     dma_segment(x_step, h_step, piecesA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -311,20 +324,29 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 #pragma unroll
         for (int g = 0; g < G; ++g) asm volatile("" : "+s"(n[0][g]), "+s"(n[1][g]));
         // ---- phase A: region A holds step t once every wave's pieces have landed
+        stamp(t, 0);
         asm volatile("s_barrier" ::: "memory");
+        stamp(t, 1);
         // the refill of the other region is issued first by the younger half of the waves (they
         // would wait for the matrix pipe anyway) and after their super-steps by the older half
         if (dma_first) dma_segment(x_step, h_step, piecesB);
+        stamp(t, 2);
         SGP_PHASE(0, if (t > t_begin) emit(G - 1, y_step - y_inc);)
+        stamp(t, 3);
         if (!dma_first) dma_segment(x_step, h_step, piecesB);
         // ---- phase B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(t, 4);
         asm volatile("s_barrier" ::: "memory");
+        stamp(t, 5);
         if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
+        stamp(t, 6);
         SGP_PHASE(1, )
+        stamp(t, 7);
         if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         // this wave's pieces of A(t+1) (and its stores) retired before the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(t, 8);
         x_step += x_inc; h_step += h_inc; y_step += y_inc;
     }
     emit(G - 1, y_step - y_inc);
@@ -336,6 +358,14 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 #undef SGP_WAITN
 #undef SGP_RD
 }
+
+#ifdef SGP_ABLATION
+unsigned* res_dbg_buffer() {
+    static unsigned* p = nullptr;
+    if (!p) { (void)hipMalloc(&p, 4 * 16 * 10 * sizeof(unsigned)); (void)hipMemset(p, 0, 4 * 16 * 10 * sizeof(unsigned)); }
+    return p;
+}
+#endif
 
 int g_res_cfg = -1;
 int res_cfg() {                                            // 0: 16 waves x 1 group, 1: 8 waves x 2 groups
@@ -362,7 +392,7 @@ int launch_res(const ResArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_res");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32)
+    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132)
 #undef SGP_ABL
 #endif
     auto kern = spmm_res<HALO, NW, G, D, PASSES>;
@@ -374,6 +404,12 @@ int launch_res(const ResArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SGP_ABLATION
+extern "C" int sgp_spmm_res_debug_read(unsigned* host) {
+    return (int)hipMemcpy(host, res_dbg_buffer(), 4 * 16 * 10 * sizeof(unsigned), hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" {
 
@@ -423,6 +459,10 @@ int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
     hipStream_t s = (hipStream_t)stream;
+    a.dbg = nullptr;
+#ifdef SGP_ABLATION
+    a.dbg = res_dbg_buffer();
+#endif
     if (res_cfg() == 1)
         return Xh ? launch_res<true, 8, 2, 4, 14>(a, s) : launch_res<false, 8, 2, 4, 14>(a, s);
     return Xh ? launch_res<true, 16, 1, 4, 7>(a, s) : launch_res<false, 16, 1, 4, 7>(a, s);

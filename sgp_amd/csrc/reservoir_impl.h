@@ -480,10 +480,13 @@ int launch_stream(ResArgs a, hipStream_t s) {
 // for the SAME 16 nodes, then exchange the new state through a double-buffered LDS slab (the
 // C-layout tile of a wave is written as-is: it is already the B-operand layout every wave
 // needs), one barrier per step.
-template <int JT, int NKX>
+constexpr int kSplitjRing = 8;       // input-row ring of the split-J kernel (time steps)
+
+template <int JT, int NKX, bool OVEC>
 __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
     static_assert(JT % 4 == 0, "split-J needs at least one j-tile per wave");
     constexpr int JW = JT / 4;                           // j-tiles per wave
+    constexpr int PFD = kSplitjRing;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const int total4 = (int)(packed_floats(JT, NKX) / 4);
@@ -494,6 +497,8 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
     const float* wx = lds + JT * 16;
     const float* wh = wx + JT * NKX * 64;
     f32x4* hbuf = reinterpret_cast<f32x4*>(lds + packed_floats(JT, NKX));   // [2][JT][64] f32x4
+    float* red_base = reinterpret_cast<float*>(hbuf + 2 * JT * 64);         // [2][64] self_norm partials
+    float* xring = red_base + 2 * 64;                                       // [PFD][NKX][64] input rows
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -514,27 +519,47 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
         }
         h[jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
     }
-    const bool o_vec = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) &&
-                       ((reinterpret_cast<uintptr_t>(a.out) & 15u) == 0);
-    __syncthreads();
 
-    // The step is a serial chain (MFMAs -> activation -> LDS exchange -> barrier), so nothing
-    // may wait for memory inside it: the input row of step t+1 is requested at the top of step
-    // t, and the state of step t-1 is stored at the top of step t -- both have a whole step to
-    // complete before the next s_waitcnt vmcnt(0) (loads and stores share that counter).
-    auto load_x = [&](int t, float (&dst)[NKX]) {
-        const float* xp = a.x + (long long)t * a.xss + (long long)node * a.xrs + q * NKX;
+    // The step is a serial chain (MFMAs -> activation -> LDS exchange -> barrier), so nothing in it
+    // may wait for HBM.  Input rows: wave 0 requests the row of step t + PFD - 1 by LDS-DMA
+    // (global_load_lds_dword, one per k-step: lane (n, q) fetches x[node n][q NKX + ks]) into a ring
+    // of PFD slots and retires the row of step t + 1 with a hand-counted vmcnt before the step's
+    // barrier, which publishes it to the other waves.  Results: the state of step t-1 is stored at
+    // the top of step t.  The barrier is a bare `s_waitcnt lgkmcnt(0); s_barrier`: hipcc's
+    // __syncthreads also drains vmcnt, i.e. waited every step (0.7-1.5 us) for the store and the
+    // input request that had just been issued.
+    bool x_ok[NKX];
+    long long x_off[NKX];
+    {
+        const int nodec = min(node, a.N - 1);
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks)
-            dst[ks] = (ok && q * NKX + ks < a.F) ? xp[ks] : 0.f;
+        for (int ks = 0; ks < NKX; ++ks) {
+            x_ok[ks] = ok && q * NKX + ks < a.F;
+            x_off[ks] = (long long)nodec * a.xrs + min(q * NKX + ks, a.F - 1);
+        }
+    }
+    const unsigned xring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) float*)xring);
+    auto dma_x = [&](int t) {
+        const float* xp = a.x + (long long)min(t, a.T - 1) * a.xss;
+        const unsigned base = xring_lds + (unsigned)((t % PFD) * NKX * 256);
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) {
+            const float* src = xp + x_off[ks];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                         :: "v"(src), "s"(base + (unsigned)ks * 256u) : "memory");
+        }
     };
+    bool st_ok[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) st_ok[w] = ok && 16 * (wave * JW + w) + 4 * q < a.R;
     auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
 #pragma unroll
         for (int w = 0; w < JW; ++w) {
             const int j0 = 16 * (wave * JW + w) + 4 * q;
-            if (ok && j0 < a.R) {
+            if (st_ok[w]) {
                 float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
-                if (o_vec) {
+                if constexpr (OVEC) {
                     *reinterpret_cast<f32x4*>(op) = hv[w];
                 } else {
 #pragma unroll
@@ -544,12 +569,16 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             }
         }
     };
-    float xr[NKX];
     f32x4 hprev[JW];
 #pragma unroll
     for (int w = 0; w < JW; ++w) hprev[w] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (a.T > 0) load_x(0, xr);
+    __syncthreads();                                     // weights in LDS
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), visible to the compiler
+    if (wave == 0) {
+        for (int p = 0; p < PFD - 1; ++p) dma_x(p);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // rows 0 .. PFD-2 published
 
     for (int t = 0; t < a.T; ++t) {
         int wo = 0;
@@ -558,10 +587,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
         const float* wx_t = wx + wo;
         const float* wh_t = wh + wo;
         if (t > 0) store_h(t - 1, hprev);
-        float xn[NKX];
-#pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xn[ks] = 0.f;
-        if (t + 1 < a.T) load_x(t + 1, xn);
+        if (wave == 0) dma_x(t + PFD - 1);               // into the slot consumed one step ago
         f32x4 acc[JW];
 #pragma unroll
         for (int w = 0; w < JW; ++w)
@@ -578,6 +604,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
                 for (int w = 0; w < JW; ++w)
                     acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[w][s], h[kb][s], acc[w], 0, 0, 0);
         }
+        const float* xrow = xring + (t % PFD) * NKX * 64;
         if constexpr (NKX % 4 == 0) {
 #pragma unroll
             for (int k4 = 0; k4 < NKX / 4; ++k4)
@@ -587,7 +614,8 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
                         wx_t + (((wave * JW + w) * (NKX / 4) + k4) * 64 + lane) * 4);
 #pragma unroll
                     for (int s = 0; s < 4; ++s)
-                        acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[s], xr[4 * k4 + s], acc[w], 0, 0, 0);
+                        acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                            wv[s], x_ok[4 * k4 + s] ? xrow[(4 * k4 + s) * 64 + lane] : 0.f, acc[w], 0, 0, 0);
                 }
         } else {
 #pragma unroll
@@ -595,7 +623,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
 #pragma unroll
                 for (int w = 0; w < JW; ++w)
                     acc[w] = __builtin_amdgcn_mfma_f32_16x16x4f32(wx_t[((wave * JW + w) * NKX + ks) * 64 + lane],
-                                                                   xr[ks], acc[w], 0, 0, 0);
+                                                                   x_ok[ks] ? xrow[ks * 64 + lane] : 0.f, acc[w], 0, 0, 0);
         }
         if (a.act == SGP_ACT_TANH) {
 #pragma unroll
@@ -618,9 +646,9 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
                 for (int r = 0; r < 4; ++r) ss = fmaf(acc[w][r], acc[w][r], ss);
             ss += __shfl_xor(ss, 16);
             ss += __shfl_xor(ss, 32);
-            float* red = reinterpret_cast<float*>(hbuf + 2 * JT * 64) + (t & 1) * 64;
+            float* red = red_base + (t & 1) * 64;
             if (q == 0) red[wave * 16 + n_in] = ss;
-            __syncthreads();
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             const float tot = red[n_in] + red[16 + n_in] + red[32 + n_in] + red[48 + n_in];
             const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
 #pragma unroll
@@ -639,9 +667,11 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             hb[jt * 64 + lane] = hn;
             hprev[w] = hn;
         }
-#pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xr[ks] = xn[ks];
-        __syncthreads();
+        // wave 0: the row of step t + 1 has landed once at most the (PFD - 2) NKX younger requests
+        // (+ this step's stores, which only make the wait stricter) are outstanding
+        if (wave == 0)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((PFD - 2) * NKX < 63 ? (PFD - 2) * NKX : 63) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (int jt = 0; jt < JT; ++jt) h[jt] = hb[jt * 64 + lane];
     }
@@ -659,7 +689,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
 
 template <int JT, int NKX>
 constexpr long long splitj_lds_bytes() {
-    return packed_floats(JT, NKX) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4;
+    return packed_floats(JT, NKX) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4 + (long long)kSplitjRing * NKX * 64 * 4;
 }
 
 template <int JT, int NKX, int NT>
@@ -708,7 +738,8 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
         if (n_tiles <= 512) {                       // up to 2 workgroups per CU: latency-bound regime
             ResArgs b = a;
             b.n_tiles = n_tiles;
-            auto kern = reservoir_layer_splitj<JT, NKX>;
+            const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+            auto kern = ov ? reservoir_layer_splitj<JT, NKX, true> : reservoir_layer_splitj<JT, NKX, false>;
             const int bytes = (int)splitj_lds_bytes<JT, NKX>();
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

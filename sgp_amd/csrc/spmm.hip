@@ -283,7 +283,9 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
                     *reinterpret_cast<f32x4*>(lds + ((p * RPP + eg) * FT + li * 4) * 4) = stage[p];
         }
         if (t > t_begin) store_rows(t - 1);
-        if constexpr (kBarrier) __syncthreads();
+        // bare barrier: hipcc's __syncthreads also drains vmcnt, i.e. it would sit out the round
+        // trip of the stores issued one line above on every step
+        if constexpr (kBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (t + 1 < t_end) issue(t + 1);          // in flight under the compute below
 
 #pragma unroll
@@ -304,7 +306,9 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
             }
             res[g] = acc;
         }
-        if constexpr (kBarrier) __syncthreads();   // all reads done before the next overwrite
+        // all reads done before the next overwrite (the staged loads of step t+1 are waited for by
+        // the ds_write that consumes them, not here)
+        if constexpr (kBarrier) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
     store_rows(t_end - 1);
 }

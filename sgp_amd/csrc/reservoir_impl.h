@@ -33,16 +33,25 @@ __host__ __device__ constexpr long long packed_floats(int JT, int NKX) {
     return (long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256;
 }
 
-// tanh(x) = sign(x) (1 - 2 / (e^{2|x|} + 1)): 6 VALU instructions, two of them quarter-rate
-// (v_exp_f32, v_rcp_f32).  fp32 MFMAs do not co-execute with VALU work on gfx950, so every
-// instruction here is matrix-pipe time: the odd-polynomial branch that used to serve |x| < 0.25
-// (10 more instructions on every value) bought relative accuracy near zero that the parity
-// criterion (absolute 1e-5, distance to fp64 of the order of the fp32 reference's own) does not
-// ask for; the absolute error of this form is ~3e-7 everywhere (tested).
-__device__ __forceinline__ float tanh_f32(float x) {
-    const float e = __builtin_amdgcn_exp2f(fabsf(x) * 2.885390081777927f);    // e^{2|x|}
-    const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-    return copysignf(t, x);
+// tanh(x) = 1 - 2 r(x), r(x) = 1 / (1 + e^{2x}): mul, v_exp_f32, add, v_rcp_f32 (two of them
+// quarter-rate) + one fma -- and the fma disappears into the leak,
+//     h' = (1-a) h + a tanh(x) = fma(-2a, r, fma(1-a, h, a)),
+// so activation + leak are 6 VALU instructions per value (8 with the sign-symmetric form used
+// before: |x|, copysign).  fp32 MFMAs do not co-execute with VALU work on gfx950 -- an instruction
+// in their shadow costs the SIMD ~10 cycles -- so every one saved is matrix-pipe time.  No branch,
+// no overflow case: e^{2x} -> inf gives r = 0, -> 0 gives r = 1.  Absolute error < 3e-7 everywhere
+// (tested); like the form before it, it trades the relative accuracy near zero that an
+// odd-polynomial branch would give (10 more instructions) -- the parity criterion is absolute.
+__device__ __forceinline__ float tanh_r(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
+}
+__device__ __forceinline__ float tanh_f32(float x) { return fmaf(-2.f, tanh_r(x), 1.f); }
+// leak with the activation value `v` (any activation), or with v = tanh_r(pre-activation)
+__device__ __forceinline__ float leak(float h, float v, float alpha, float one_minus_alpha) {
+    return one_minus_alpha * h + alpha * v;
+}
+__device__ __forceinline__ float leak_tanh_r(float h, float r, float alpha, float one_minus_alpha) {
+    return fmaf(-2.f * alpha, r, fmaf(one_minus_alpha, h, alpha));
 }
 
 struct ResArgs {
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_f32(acc[jt][r]);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
             } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
@@ -212,7 +221,8 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
             for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    h[i][jt][r] = a.one_minus_alpha * h[i][jt][r] + a.alpha * acc[jt][r];
+                    h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
+                                                        : leak(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
                 const int j0 = 16 * jt + 4 * q;
                 if (ok[i] && j0 < a.R) {
                     float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
@@ -397,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_f32(acc[i][jt][r]);
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
             } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
@@ -421,7 +431,8 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
             for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    h[i][jt][r] = a.one_minus_alpha * h[i][jt][r] + a.alpha * acc[i][jt][r];
+                    h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha)
+                                                        : leak(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha);
                 const int j0 = 16 * jt + 4 * q;
                 if (ok[i]) {                                  // R == 16 JT (host check)
                     float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[w][r] = tanh_f32(acc[w][r]);
+                for (int r = 0; r < 4; ++r) acc[w][r] = tanh_r(acc[w][r]);
         } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)
@@ -663,7 +674,8 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             f32x4 hn;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                hn[r] = a.one_minus_alpha * h[jt][r] + a.alpha * acc[w][r];
+                hn[r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[jt][r], acc[w][r], a.alpha, a.one_minus_alpha)
+                                              : leak(h[jt][r], acc[w][r], a.alpha, a.one_minus_alpha);
             hb[jt * 64 + lane] = hn;
             hprev[w] = hn;
         }

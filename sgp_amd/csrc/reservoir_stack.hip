@@ -316,7 +316,7 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_f32(acc[jt][r]);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
             } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
@@ -341,7 +341,8 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[jt][r] = om * h[jt][r] + al * acc[jt][r];
+                for (int r = 0; r < 4; ++r)
+                    h[jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[jt][r], acc[jt][r], al, om) : leak(h[jt][r], acc[jt][r], al, om);
                 if (l + 1 < L) dst[jt * 64 + lane] = h[jt];
             }
         }

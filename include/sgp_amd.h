@@ -290,6 +290,12 @@ int sgp_reservoir_fused_f32(const float* x, int64_t x_row_stride, int64_t x_step
  *                        the [T, N, L*R] embedding).  z, p, h_in, h_out: contiguous [N, R].
  */
 int64_t sgp_gesn_workspace_bytes(int32_t N, int32_t R, int32_t L);
+/* sgp_gesn_tune(persistent): 1 (default, also SGP_GESN_PERSISTENT=1) lets sgp_gesn_f32 run the
+ * sequence in ONE cooperative launch per 256 steps when the shape allows it (R % 16 == 0, R <= 384,
+ * L <= 8, the (layer, column group, row tile) items fit one workgroup per CU; csrc/gesn_persist.hip:
+ * layers as a wavefront, weights in registers, one grid barrier per step); 0 = always two launches
+ * per (step, layer); < 0 = query.  Returns the setting. */
+int sgp_gesn_tune(int32_t persistent);
 int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                  const float* x, int64_t x_row_stride, int64_t x_step_stride,
                  const float* const* w_ih, const float* const* w_hh, const float* const* b,

@@ -10,6 +10,18 @@
 
 using sgp::f32x4;
 
+// gesn_persist.hip
+namespace sgp_gesn {
+struct PArgs;
+int mode();
+long long packed_floats(int R, int L);
+int pack(const float* wcat, float* wpk, int R, int L, hipStream_t stream);
+int run_chunk(const int32_t* rowptr, const int32_t* col, const float* val, const float* p0,
+              const float* wcat, const float* wpk, const float* bcat, float* cbuf, float* h_state, float* out,
+              long long ors, long long oss, unsigned* bar, const double* alpha, int act,
+              int tc, int N, int R, int L, hipStream_t stream);
+}
+
 namespace {
 
 // C[m, n] = sum_k A[m, k] * W[n, k] (+ bias[n]);  one 256-thread block per 16 x 16 output tile,
@@ -173,18 +185,22 @@ int launch_update(const int32_t* rowptr, const int32_t* col, const float* val,
 constexpr int kStepChunk = 256;            // steps of layer-0 input term computed per GEMM
 
 struct GesnWorkspace {                      // offsets in floats
-    long long wcat, bcat, c, hb, p0, total;
+    long long wcat, bcat, c, hb, p0, bar, wpk, total;
     GesnWorkspace(long long N, long long R, long long L) {
         wcat = 0;                           // L x [2R, R]   rows 0..R-1 = W_hh,i; R..2R-1 = W_ih,i+1
         bcat = wcat + L * 2 * R * R;        // L x [2R]      zeros | b_{i+1}
-        c = bcat + L * 2 * R;               // L x [N, 2R]   z_i | p_{i+1}
-        hb = c + L * N * 2 * R;             // [L, N, R]     ping-pong partner of h_state
+        c = bcat + L * 2 * R;               // 2 x L x [N, 2R]   z_i | p_{i+1}  (the persistent kernel
+                                            // alternates two planes by tick; the stepwise path uses one)
+        hb = c + 2 * L * N * 2 * R;         // [L, N, R]     ping-pong partner of h_state
         p0 = hb + L * N * R;                // [kStepChunk, N, R]
-        total = p0 + (long long)kStepChunk * N * R;
+        bar = (p0 + (long long)kStepChunk * N * R + 3) / 4 * 4;   // grid barrier words
+        wpk = bar + 512;                    // (kBarWords of gesn_persist.hip = 272); packed weight fragments
+        total = wpk + (R % 16 == 0 && R <= 384 ? sgp_gesn::packed_floats((int)R, (int)L) : 0);
     }
 };
 
 }  // namespace
+
 
 extern "C" {
 
@@ -252,24 +268,62 @@ int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
     auto bcat = [&](int i) { return base + ws.bcat + (size_t)i * 2 * R; };
     auto cbuf = [&](int i) { return base + ws.c + (size_t)i * N * 2 * R; };
     auto n_out = [&](int i) { return i + 1 < L ? 2 * R : R; };
+    const size_t NR = (size_t)N * R;
+    const bool x_flat = x_step_stride == (int64_t)N * x_row_stride;
+    int rc = 0;
+    auto input_term = [&](int t0, int tc) {      // p_0 of steps t0 .. t0 + tc - 1 -> ws.p0
+        float* p0 = base + ws.p0;
+        if (x_flat)
+            return launch_gemm(x + (size_t)t0 * x_step_stride, x_row_stride, w_ih[0], F, b[0], p0, R,
+                               tc * N, R, F, stream);
+        int r = 0;
+        for (int s = 0; s < tc && !r; ++s)
+            r = launch_gemm(x + (size_t)(t0 + s) * x_step_stride, x_row_stride, w_ih[0], F, b[0],
+                            p0 + s * NR, R, N, R, F, stream);
+        return r;
+    };
+    // ---- persistent path: one cooperative launch per chunk of steps (gesn_persist.hip); a refused
+    // launch (shape not served, device busy with another cooperative kernel) leaves the rest of the
+    // sequence to the stepwise path below, which restarts from h_state
+    int t_done = 0;
+    bool used_persistent = false;
+    if (sgp_gesn::mode()) {
+        for (; t_done < T && !rc; t_done += kStepChunk) {
+            const int tc = T - t_done < kStepChunk ? T - t_done : kStepChunk;
+            rc = input_term(t_done, tc);
+            if (rc) break;
+            if (t_done == 0 && R % 16 == 0 && R <= 384) {
+                rc = sgp_gesn::pack(base + ws.wcat, base + ws.wpk, R, L, stream);
+                if (rc) break;
+            }
+            const int r = sgp_gesn::run_chunk(rowptr, col, val, base + ws.p0, base + ws.wcat, base + ws.wpk, base + ws.bcat,
+                                              base + ws.c, h_state, out + (size_t)t_done * out_step_stride,
+                                              out_row_stride, out_step_stride,
+                                              reinterpret_cast<unsigned*>(base + ws.bar), alpha, act,
+                                              tc, N, R, L, stream);
+            if (r > 0) break;                      // refused: nothing was launched for this chunk
+            if (r < 0) return r;
+            used_persistent = true;
+        }
+        if (rc) return rc;
+        if (used_persistent) {
+            unsigned failed = 0;
+            e = hipMemcpyAsync(&failed, reinterpret_cast<unsigned*>(base + ws.bar) + 1, sizeof(unsigned),
+                               hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return sgp::fail((int)e, "sgp_gesn_f32: %s", hipGetErrorString(e));
+            if (failed) return sgp::fail(SGP_EUNSUP, "sgp_gesn_f32: grid barrier of the persistent kernel timed out");
+        }
+        if (t_done >= T) return 0;
+    }
     float* hcur = h_state;
     float* hnext = base + ws.hb;
-    const size_t NR = (size_t)N * R;
-    int rc = 0;
     for (int i = 0; i < L && !rc; ++i)        // z_i for the first step from the initial states
         rc = launch_gemm(hcur + i * NR, R, wcat(i), R, bcat(i), cbuf(i), 2 * R, N, R, R, stream);
-    const bool x_flat = x_step_stride == (int64_t)N * x_row_stride;
-    for (int t0 = 0; t0 < T && !rc; t0 += kStepChunk) {
+    for (int t0 = t_done; t0 < T && !rc; t0 += kStepChunk) {
         const int tc = T - t0 < kStepChunk ? T - t0 : kStepChunk;
         float* p0 = base + ws.p0;
-        if (x_flat) {
-            rc = launch_gemm(x + (size_t)t0 * x_step_stride, x_row_stride, w_ih[0], F, b[0], p0, R,
-                             tc * N, R, F, stream);
-        } else {
-            for (int s = 0; s < tc && !rc; ++s)
-                rc = launch_gemm(x + (size_t)(t0 + s) * x_step_stride, x_row_stride, w_ih[0], F, b[0],
-                                 p0 + s * NR, R, N, R, F, stream);
-        }
+        rc = input_term(t0, tc);
         for (int s = 0; s < tc && !rc; ++s) {
             float* out_t = out + (size_t)(t0 + s) * out_step_stride;
             for (int i = 0; i < L && !rc; ++i) {

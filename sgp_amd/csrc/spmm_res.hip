@@ -47,12 +47,16 @@ struct ResArgs {
 constexpr int SH = 20;                     // super-steps per range held in registers (80 columns)
 constexpr int WH = (SH + 3) / 4;           // weight registers per range
 
+// cache policy bits of the staging reads (experiment builds: -DSGP_DMA_MOD='" sc0"' etc.)
+#ifndef SGP_DMA_MOD
+#define SGP_DMA_MOD ""
+#endif
 __device__ __forceinline__ void dma16_saddr(unsigned voff, const void* sbase, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" SGP_DMA_MOD
                  :: "v"(voff), "s"(sbase), "s"(lds_off) : "memory");
 }
 __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" SGP_DMA_MOD
                  :: "v"(vaddr), "s"(lds_off) : "memory");
 }
 

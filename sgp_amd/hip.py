@@ -89,6 +89,7 @@ SIGNATURES = {
                                                c_p, c_p,
                                                c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_gesn_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
+    "sgp_gesn_tune": (ctypes.c_int, [c_i32]),
     "sgp_gesn_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
                                     c_p, c_i64, c_i64, c_p, c_p,
                                     c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),

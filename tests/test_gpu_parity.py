@@ -440,6 +440,45 @@ def test_gesn_long_sequence():
     assert e_gpu < max(5e-6, 2 * e_cpu), (e_gpu, e_cpu)
 
 
+@pytest.mark.parametrize("n,f,r,L,act,t", [(207, 2, 320, 3, "tanh", 40), (325, 2, 320, 3, "tanh", 9),
+                                            (70, 3, 64, 1, "relu", 300), (33, 1, 512, 2, "self_norm", 12),
+                                            (500, 2, 48, 4, "tanh", 20), (16, 2, 16, 8, "tanh", 5)])
+def test_gesn_persistent_kernel_equals_stepwise_path(n, f, r, L, act, t):
+    """The one-launch-per-256-steps kernel (csrc/gesn_persist.hip: layer wavefront, weights in
+    registers, grid barrier per step) against the two-launches-per-(step, layer) path: the same
+    products in another summation order of the K split, so 1e-5; states carried identically."""
+    from sgp_amd import hip
+    from sgp_amd.nn.encoders.dyn_gesn_encoder import gesn_operator
+    lib = hip.load()
+    torch.manual_seed(n + r)
+    ei, ew = synthetic.sparse_traffic_graph(n, 7 * n, seed=n)
+    res = sgp_amd.GraphESN(f, r, num_layers=L, leaking_rate=0.9, spectral_radius=0.9, density=0.7,
+                           activation=act, alpha_decay=True)
+    op = gesn_operator(ei, ew, n)
+    x = torch.randn(1, t, n, f).cuda()
+    try:
+        assert lib.sgp_gesn_tune(1) == 1
+        y1, h1 = res(x, op)
+        assert lib.sgp_gesn_tune(0) == 0
+        y0, h0 = res(x, op)
+    finally:
+        lib.sgp_gesn_tune(1)
+    assert torch.isfinite(y1).all()
+    # the recurrence does not contract (DESIGN 2): both paths are held to the fp32 oracle's own distance
+    # from the fp64 evaluation, and to each other at that scale
+    layers = [dict(w_ih=l.w_ih.data, w_hh=l.w_hh.data, b_ih=l.b_ih.data, alpha=float(l.alpha))
+              for l in res.rnn_cells]
+    ref = O.gesn_forward(x[0].cpu(), ei, ew, layers, activation=act)
+    ref64 = O.gesn_forward(x[0].cpu(), ei, ew, layers, activation=act, dtype=torch.float64)
+    e_cpu = float((ref.double() - ref64).abs().max())
+    e1 = float((y1[0].double().cpu() - ref64).abs().max())
+    e0 = float((y0[0].double().cpu() - ref64).abs().max())
+    assert e1 < max(5e-6, 2 * e_cpu) and e0 < max(5e-6, 2 * e_cpu), (e1, e0, e_cpu)
+    tol = max(1e-5, 4 * e_cpu)
+    close(y1, y0, rtol=tol, atol=tol, fro=1e-5)
+    close(h1, h0, rtol=tol, atol=tol, fro=1e-5)
+
+
 def test_graph_esn_module_and_layer_step():
     torch.manual_seed(9)
     n, f, r = 40, 3, 48

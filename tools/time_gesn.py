@@ -11,10 +11,16 @@ ei, ew = synthetic.sparse_traffic_graph(n, 1515, seed=0)
 torch.manual_seed(0)
 enc = sgp_amd.GESNEncoder(f, r, L, .9, .9, .7, 1., True)
 x = torch.randn(T, n, f, device="cuda")
-enc(x[:50], ei, ew)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-y = enc(x, ei, ew)
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"gesn T={T} N={n} R={r} L={L}: {dt*1e3:.1f} ms, {dt/T*1e6:.1f} us/step, {T*n/dt:.3e} node-steps/s")
+from sgp_amd import hip
+lib = hip.load()
+for mode in (1, 0):
+    lib.sgp_gesn_tune(mode)
+    enc(x[:50], ei, ew)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    y = enc(x, ei, ew)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"gesn {'persistent' if mode else 'stepwise  '} T={T} N={n} R={r} L={L}: {dt*1e3:.1f} ms, {dt/T*1e6:.1f} us/step, "
+          f"{T*n/dt:.3e} node-steps/s", flush=True)
+lib.sgp_gesn_tune(1)

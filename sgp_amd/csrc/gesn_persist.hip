@@ -35,7 +35,7 @@ namespace sgp_gesn {
 
 constexpr int kMaxLayers = 8;
 constexpr int kMaxRT = 4;                  // row tiles per workgroup
-constexpr int kEdgeCap = 4096;             // adjacency entries cached in LDS per workgroup
+constexpr int kEdgeCap = 1024;             // adjacency entries cached in LDS per workgroup (else read from global)
 
 struct PArgs {
     const int* rowptr; const int* col; const float* val;

@@ -6,8 +6,9 @@ import sgp_amd
 from sgp_amd import synthetic
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-n, f, r, L = 207, 2, 320, 3
-ei, ew = synthetic.sparse_traffic_graph(n, 1515, seed=0)
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 207          # 325 = PEMS-BAY shape
+f, r, L = 2, 320, 3
+ei, ew = synthetic.sparse_traffic_graph(n, {207: 1515, 325: 2369}.get(n, 7 * n), seed=0)
 torch.manual_seed(0)
 enc = sgp_amd.GESNEncoder(f, r, L, .9, .9, .7, 1., True)
 x = torch.randn(T, n, f, device="cuda")

@@ -166,6 +166,29 @@ __device__ __forceinline__ void edge_half_dpp(const char* lds, int off, float w,
     }
 }
 
+// Quarter batch (4 rotations) for the tall-tile form, where registers are short: 20 temporaries
+// instead of 40.
+template <int S0>
+__device__ __forceinline__ void edge_quarter_dpp(const char* lds, int off, float w, int li16, f32x4& acc) {
+    int ad[4];
+    f32x4 xv[4];
+#define SGP_ROT(i) ad[i] = ror_i<S0 + i>(off) + li16;
+    SGP_ROT(0) SGP_ROT(1) SGP_ROT(2) SGP_ROT(3)
+#undef SGP_ROT
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(lds + ad[i]);
+    if constexpr (S0 == 0) {
+        acc += w * xv[0];
+        SGP_STEP_ROR(1, 1) SGP_STEP_ROR(2, 2) SGP_STEP_ROR(3, 3)
+    } else if constexpr (S0 == 4) {
+        SGP_STEP_ROR(4, 0) SGP_STEP_ROR(5, 1) SGP_STEP_ROR(6, 2) SGP_STEP_ROR(7, 3)
+    } else if constexpr (S0 == 8) {
+        SGP_STEP_ROR(8, 0) SGP_STEP_ROR(9, 1) SGP_STEP_ROR(10, 2) SGP_STEP_ROR(11, 3)
+    } else {
+        SGP_STEP_ROR(12, 0) SGP_STEP_ROR(13, 1) SGP_STEP_ROR(14, 2) SGP_STEP_ROR(15, 3)
+    }
+}
+
 struct TiledArgs {
     const int* trow; const int* uptr; const int* ucol; const int* erow; const unsigned short* ecol; const float* eval;
     int tile_rows, n_tiles;
@@ -173,6 +196,7 @@ struct TiledArgs {
     float* Y; long long yrs, ybs;
     int n_rows, batch, feat;
     int t_chunk, n_tchunks;
+    int stage_bytes;                   // tall tiles: the edge records live in LDS behind the stage
 };
 
 // Feature tile FT = 64 floats (16 lanes x 16 B per staged row).  NTHR threads = NTHR/16 edge
@@ -223,12 +247,17 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     const int t_end = min(a.batch, t_begin + a.t_chunk);
     if (t_begin >= t_end) return;
 
-    // my rows' edge records -> registers (LDS byte offset of the source row + weight)
+    // my rows' edge records -> registers (LDS byte offset of the source row + weight).  Tall tiles
+    // (RPG > 2: small sparse graphs staged whole, see graph.ShiftOperator.tile_plan) keep them in LDS
+    // behind the stage instead -- 2 RPG NB registers would spill -- as u16 staged-row index + weight.
+    constexpr bool TALL = RPG > 2;
     const int row0 = a.trow[tile];
     const int rows_here = a.trow[tile + 1] - row0;
-    int eoff[RPG][NB];
-    float ewv[RPG][NB];
+    int eoff[TALL ? 1 : RPG][NB];
+    float ewv[TALL ? 1 : RPG][NB];
     int nbat[RPG];
+    float* rec_w = reinterpret_cast<float*>(lds + a.stage_bytes);                         // [RPG * NEG][NB][16]
+    unsigned short* rec_o = reinterpret_cast<unsigned short*>(rec_w + RPG * NEG * NB * 16);
 #pragma unroll
     for (int g = 0; g < RPG; ++g) {
         const int rr = eg + g * NEG;
@@ -238,8 +267,13 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
 #pragma unroll
         for (int n = 0; n < NB; ++n) {
             const bool on = n < nbat[g];
-            eoff[g][n] = on ? (int)a.ecol[eb + n * 16 + li] * (FT * 4) : 0;
-            ewv[g][n] = on ? a.eval[eb + n * 16 + li] : 0.f;
+            if constexpr (TALL) {
+                rec_w[(rr * NB + n) * 16 + li] = on ? a.eval[eb + n * 16 + li] : 0.f;
+                rec_o[(rr * NB + n) * 16 + li] = on ? a.ecol[eb + n * 16 + li] : (unsigned short)0;
+            } else {
+                eoff[g][n] = on ? (int)a.ecol[eb + n * 16 + li] * (FT * 4) : 0;
+                ewv[g][n] = on ? a.eval[eb + n * 16 + li] : 0.f;
+            }
         }
     }
 
@@ -294,13 +328,26 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
 #pragma unroll
             for (int n = 0; n < NB; ++n) {
                 if (n < nbat[g]) {
-                    if constexpr (VARIANT >= 1) {
-                        constexpr int ABL = (VARIANT == 2 || VARIANT == 3) ? VARIANT : 0;
-                        edge_half_dpp<0, ABL>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
-                        edge_half_dpp<8, ABL>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                    int eo; float ew;
+                    if constexpr (TALL) {
+                        const int rr = eg + g * NEG;
+                        eo = (int)rec_o[(rr * NB + n) * 16 + li] * (FT * 4);
+                        ew = rec_w[(rr * NB + n) * 16 + li];
                     } else {
-                        edge_half<0>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
-                        edge_half<8>(lds, eoff[g][n], ewv[g][n], li * 16, acc);
+                        eo = eoff[g][n]; ew = ewv[g][n];
+                    }
+                    if constexpr (TALL) {
+                        edge_quarter_dpp<0>(lds, eo, ew, li * 16, acc);
+                        edge_quarter_dpp<4>(lds, eo, ew, li * 16, acc);
+                        edge_quarter_dpp<8>(lds, eo, ew, li * 16, acc);
+                        edge_quarter_dpp<12>(lds, eo, ew, li * 16, acc);
+                    } else if constexpr (VARIANT >= 1) {
+                        constexpr int ABL = (VARIANT == 2 || VARIANT == 3) ? VARIANT : 0;
+                        edge_half_dpp<0, ABL>(lds, eo, ew, li * 16, acc);
+                        edge_half_dpp<8, ABL>(lds, eo, ew, li * 16, acc);
+                    } else {
+                        edge_half<0>(lds, eo, ew, li * 16, acc);
+                        edge_half<8>(lds, eo, ew, li * 16, acc);
                     }
                 }
             }
@@ -555,7 +602,10 @@ int tiled_variant() {
 
 template <int RPG, int NB, bool HALO, int VARIANT>
 int launch_tiled_v(const TiledArgs& a, hipStream_t s) {
-    const size_t lds_bytes = (size_t)kTiledCapacity * 64 * 4;
+    const size_t lds_bytes = RPG > 2 ? (size_t)a.stage_bytes + (size_t)RPG * kTiledGroups * NB * 16 * 6
+                                     : (size_t)kTiledCapacity * 64 * 4;
+    if (lds_bytes > 160 * 1024)
+        return sgp::fail(SGP_EUNSUP, "spmm_tiled: tall tile needs %zu bytes of LDS (stage + edge records)", lds_bytes);
     auto kern = spmm_tiled<kTiledThreads, kTiledPasses, RPG, NB, HALO, VARIANT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -582,7 +632,7 @@ int launch_tiled(const TiledArgs& a, hipStream_t s) {
 template <bool HALO>
 int dispatch_tiled(const TiledArgs& a, int rpg, int nb, hipStream_t s) {
 #define SGP_T(R, B) if (rpg == R && nb == B) return launch_tiled<R, B, HALO>(a, s);
-    SGP_T(1, 2) SGP_T(2, 2) SGP_T(1, 8)
+    SGP_T(1, 2) SGP_T(2, 2) SGP_T(1, 8) SGP_T(4, 1) SGP_T(6, 1) SGP_T(4, 2) SGP_T(6, 2)
 #undef SGP_T
     return sgp::fail(SGP_EUNSUP, "spmm_tiled: no kernel for rows/group=%d batches=%d", rpg, nb);
 }
@@ -594,7 +644,7 @@ extern "C" {
 int32_t sgp_spmm_tiled_max_union(int32_t feat) {
     return (feat > 0 && feat % 64 == 0) ? kTiledCapacity : 0;
 }
-int32_t sgp_spmm_tiled_max_tile_rows(void) { return 2 * kTiledGroups; }
+int32_t sgp_spmm_tiled_max_tile_rows(void) { return 6 * kTiledGroups; }   // (rows / group 1, 2, 4, 6)
 int32_t sgp_spmm_tiled_max_row_edges(void) { return 8 * 16; }
 
 int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val,
@@ -680,8 +730,10 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
     if (tc > batch) tc = batch;
     a.t_chunk = tc;
     a.n_tchunks = (batch + tc - 1) / tc;
-    const int rpg = (tile_rows + kTiledGroups - 1) / kTiledGroups;
-    const int nb = max_row_edges <= 32 ? 2 : 8;
+    a.stage_bytes = ((max_union + 63) / 64 * 64) * 256;   // whole passes of 64 staged rows
+    int rpg = (tile_rows + kTiledGroups - 1) / kTiledGroups;
+    rpg = rpg <= 2 ? rpg : (rpg <= 4 ? 4 : 6);          // (the kernel masks the rows a group does not have)
+    const int nb = (rpg > 2 && max_row_edges <= 16) ? 1 : (max_row_edges <= 32 ? 2 : 8);
     hipStream_t s = (hipStream_t)stream;
     return Xh ? dispatch_tiled<true>(a, rpg, nb, s) : dispatch_tiled<false>(a, rpg, nb, s);
 }

@@ -142,10 +142,14 @@ class ShiftOperator:
             self._dev[key] = (self.rowptr.to(device), self.col.to(device), self.val.to(device))
         return self._dev[key]
 
-    def tile_plan(self, feat, device, limits=None):
+    def tile_plan(self, feat, device, limits=None, tall=True):
         """Tile plan for feature width ``feat`` on ``device`` or None when the graph
-        has no exploitable locality (then the generic CSR kernel is used)."""
+        has no exploitable locality (then the generic CSR kernel is used).  ``tall=False``: the
+        plan with <= 64-row tiles that every LDS-staged kernel accepts, even where a tall-tile plan
+        (VALU kernel only) exists."""
         key = (feat % 64 == 0, str(device))
+        if not tall and key in self._plans and (key, "std") in self._plans:
+            return self._plans[(key, "std")]
         if key not in self._plans:
             plan = None
             if feat % 64 == 0 and self.nnz() > 0:
@@ -164,6 +168,30 @@ class ShiftOperator:
                                                self.num_nodes, order, **limits)
                     if alt is not None and (plan is None or alt.tile_rows > plan.tile_rows):
                         plan = alt
+                # Sparse graphs (4-row groups share few columns: the VALU kernel serves them) gain from
+                # TALL tiles: a tile stages every distinct source row of its rows once per step, so a
+                # small traffic graph as ONE tile (325 rows: the whole slab of a step, 83 KB, in LDS)
+                # stages each row once instead of once per 64-row tile (3.9x at 325 nodes).
+                if plan is not None and not plan.reordered and plan.tile_rows <= 64 and \
+                        (plan.gw is None or plan.group_fill < 0.5) and limits.get("max_tile_rows", 64) <= 64 \
+                        and plan.max_row_edges <= 32:
+                    from . import hip
+                    tl = hip.tall_tile_limits(feat)
+                    for tr in (384, 320, 256, 192, 128):
+                        if tr > tl["max_tile_rows"]:
+                            continue
+                        # LDS: staged rows (whole passes of 64) + 6 bytes per edge slot of the tile's rows
+                        rpg = 4 if tr <= 256 else 6
+                        nb = 1 if plan.max_row_edges <= 16 else 2
+                        room = 160 * 1024 - rpg * 64 * nb * 16 * 6
+                        mu = min(tl["max_union"], room // (64 * 256) * 64)
+                        tp = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                             self.num_nodes, mu, tl["max_tile_rows"], 32,
+                                             candidates=(tr,)) if mu >= tr // 2 else None
+                        if tp is not None and tp.tile_rows > 128:
+                            self._plans[(key, "std")] = plan.to(device)
+                            plan = tp
+                            break
                 if plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
@@ -176,7 +204,7 @@ class ShiftOperator:
         key = ("blk", feat % 64 == 0, str(device))
         if key not in self._plans:
             plan = None
-            base = self.tile_plan(feat, device)
+            base = self.tile_plan(feat, device, tall=False)
             if base is not None and base.gw is not None and base.group_fill >= 0.5 and \
                     self.num_nodes >= 256:
                 from . import hip, rowblock
@@ -209,7 +237,7 @@ class ShiftOperator:
                              f"{self.num_cols} columns, {y.shape[1]} result rows for {self.num_nodes}")
         if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
             raise ValueError("halo batch / feature size differs from x")
-        plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device)
+        plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # row-block kernel: on request only (measured on the target graph: better compute, 10.3 vs
         # 10.7 ms per 512 steps without staging, but its 128-row tiles halve the number of time
         # steps of an XCD's working set that fit the L2 -- 14.9 vs 12.8 ms with staging)

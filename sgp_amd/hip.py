@@ -348,6 +348,14 @@ def tiled_limits(feat):
                 max_row_edges=lib.sgp_spmm_tiled_max_row_edges())
 
 
+def tall_tile_limits(feat):
+    """Limits of the VALU kernel alone (sgp_spmm_tiled_f32): tiles of up to 512 rows, 8 per edge group."""
+    lib = load()
+    return dict(max_union=lib.sgp_spmm_tiled_max_union(feat),
+                max_tile_rows=lib.sgp_spmm_tiled_max_tile_rows(),
+                max_row_edges=lib.sgp_spmm_tiled_max_row_edges())
+
+
 # ---------------------------------------------------------------- reservoir
 _WORKSPACES = {}
 

@@ -100,6 +100,38 @@ def test_spmm_tiled_knn(n, k, feat):
     close(y, y2, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,e,feat,t", [(207, 1515, 64, 70), (325, 2369, 128, 40), (383, 2000, 64, 33),
+                                         (130, 900, 192, 9), (700, 4900, 64, 12)])
+def test_sparse_graphs_take_tall_tiles(n, e, feat, t):
+    """Traffic-sized sparse graphs (METR-LA / PEMS-BAY shapes): the VALU kernel stages the whole slab
+    of a step once per workgroup (tiles of up to 384 rows, edge records in LDS) -- against the dense
+    product, the CSR kernel and the 64-row plan; rows without edges, ragged degrees, duplicate edges."""
+    torch.manual_seed(n)
+    ei, ew = synthetic.sparse_traffic_graph(n, e, seed=n)
+    ei[:, :5] = ei[:, 5:10]                                        # duplicate entries are summed
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    plan = op.tile_plan(feat, torch.device("cuda"))
+    assert plan is not None
+    if n <= 384:                           # (700 random nodes: no tile of > 128 rows fits the stage)
+        assert 128 < plan.tile_rows <= 384 and plan.gw is None
+    assert op.tile_plan(feat, torch.device("cuda"), tall=False).tile_rows <= 64
+    x = torch.randn(t, n, feat)
+    ref = dense_ref(op, x)
+    y = torch.full((t, n, feat), float("nan"), device="cuda")
+    op.propagate(x.cuda(), y)
+    assert op.last_kernel == "spmm_tiled"
+    close(y, ref)
+    for force in ("csr", "mfma", "res", "tiled"):
+        y2 = torch.full((t, n, feat), float("nan"), device="cuda")
+        op.propagate(x.cuda(), y2, force=force)
+        close(y2, ref)
+    # strided in-place slots of a wider embedding, as the encoder uses them
+    emb = torch.randn(t, n, 3 * feat, device="cuda")
+    want = dense_ref(op, emb[:, :, :feat].cpu())
+    op.propagate(emb[:, :, :feat], emb[:, :, feat:2 * feat])
+    close(emb[:, :, feat:2 * feat], want)
+
+
 def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     torch.manual_seed(5)
     n, feat, t = 700, 64, 70                      # t > one time chunk

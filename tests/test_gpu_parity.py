@@ -130,6 +130,16 @@ def test_sparse_graphs_take_tall_tiles(n, e, feat, t):
     want = dense_ref(op, emb[:, :, :feat].cpu())
     op.propagate(emb[:, :, :feat], emb[:, :, feat:2 * feat])
     close(emb[:, :, feat:2 * feat], want)
+    # the local blocks of a 2-rank node partition (halo rows as the second source)
+    from sgp_amd import partition
+    bounds = partition.partition_bounds(n, 2)
+    for r in range(2):
+        blk = partition.split_operator(op, bounds, r)
+        xo = x[:, blk.lo:blk.hi].cuda().contiguous()
+        recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()
+        yb = torch.full((t, blk.n_own, feat), float("nan"), device="cuda")
+        blk.op.propagate(xo, yb, halo=recv.permute(1, 0, 2) if blk.n_halo else None)
+        close(yb, ref[:, blk.lo:blk.hi])
 
 
 def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():

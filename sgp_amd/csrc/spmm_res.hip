@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
     constexpr int kStageBytes = PASSES * RPP * 256;
     const int tile_q0 = a.gptr[tile * (2 * GT)], tile_q1 = a.gptr[tile * (2 * GT) + 2 * GT];
     const int tile_quads = tile_q1 - tile_q0;
-    {
+    if constexpr ((ABL & 8) == 0) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
         f32x4* dst = reinterpret_cast<f32x4*>(lds + kStageBytes);
         for (int i = tid; i < tile_quads * 16; i += NW * 64) dst[i] = src[i];
@@ -158,6 +158,32 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         for (int i = tid; i < tile_quads * 4; i += NW * 64) idst[i] = isrc[i];
     }
 
+    // (ablation 8: per-lane source offsets of EVERY piece, for the wave that issues all staging reads;
+    // the table takes the place of the LDS copy of the stream, long ranges are cut at SH)
+    unsigned* dma_tab = reinterpret_cast<unsigned*>(lds + kStageBytes);
+    if constexpr ((ABL & 8) != 0) {
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < PASSES; ++p) dma_tab[p * (NW * 64) + tid] = voff[p];
+    }
+    // ablation 8: the last wave issues every piece of a segment (the others none)
+    auto dma_all = [&](const char* xt, bool seg_b) {
+        if constexpr ((ABL & 8) != 0) {
+#pragma unroll
+            for (int p = 0; p < PASSES; ++p) {
+                unsigned vo[NW];
+#pragma unroll
+                for (int v = 0; v < NW; ++v) vo[v] = dma_tab[p * (NW * 64) + v * 64 + lane];
+#pragma unroll
+                for (int v = 0; v < NW; ++v) {
+                    const int r0 = p * RPP + v * 4;
+                    const bool in_a = r0 < uA, in_b = r0 >= uA && r0 < nU;
+                    if (seg_b ? in_b : in_a)
+                        dma16_saddr(vo[v], xt, __builtin_amdgcn_readfirstlane(lds0 + (unsigned)v * 1024u + (unsigned)p * (unsigned)(RPP * 256)));
+                }
+            }
+        }
+    };
     // ---- the wave's stream -> registers (once per workgroup)
     // weights: lane (q, b = li >> 2, i = li & 3) holds row i's weight for class q's column in
     // super-step 4 p + b (gw is stored one float per lane and quad: the MFMA of super-step s takes
@@ -179,6 +205,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         for (int ph = 0; ph < 2; ++ph) {
             const int qb = ph ? q1 : q0, qe = ph ? q2 : q1;
             n[ph][g] = __builtin_amdgcn_readfirstlane(a.gsup[grp + ph]);
+            if constexpr ((ABL & 64) != 0) { if (n[ph][g] > SH) n[ph][g] = SH; if (wave == NW - 1) n[ph][g] = 0; }
             qrel[ph][g] = qb - tile_q0;
 #pragma unroll
             for (int p = 0; p < WH; ++p)
@@ -319,9 +346,11 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
     };
 
     __syncthreads();
-    dma_segment(x_step, h_step, piecesA);
+    constexpr bool kOneIssuer = (ABL & 8) != 0;
+    if constexpr (kOneIssuer) { if (wave == NW - 1) dma_all(x_step, false); }
+    else dma_segment(x_step, h_step, piecesA);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const bool dma_first = wave >= NW / 2;
+    const bool dma_first = kOneIssuer ? false : wave >= NW / 2;
     for (int t = t_begin; t < t_end; ++t) {
         // the range lengths are re-made opaque every step: otherwise hipcc hoists all exit
         // comparisons out of the time loop as 64-bit masks and spills them to VGPR lanes
@@ -334,20 +363,22 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         // the refill of the other region is issued first by the younger half of the waves (they
         // would wait for the matrix pipe anyway) and after their super-steps by the older half
         if (dma_first) dma_segment(x_step, h_step, piecesB);
+        if constexpr (kOneIssuer) { if (wave == NW - 1) dma_all(x_step, true); }
         stamp(t, 2);
         SGP_PHASE(0, if (t > t_begin) emit(G - 1, y_step - y_inc);)
         stamp(t, 3);
-        if (!dma_first) dma_segment(x_step, h_step, piecesB);
+        if (!kOneIssuer && !dma_first) dma_segment(x_step, h_step, piecesB);
         // ---- phase B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(t, 4);
         asm volatile("s_barrier" ::: "memory");
         stamp(t, 5);
         if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
+        if constexpr (kOneIssuer) { if (wave == NW - 1 && t + 1 < t_end) dma_all(x_step + x_inc, false); }
         stamp(t, 6);
         SGP_PHASE(1, )
         stamp(t, 7);
-        if (!dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
+        if (!kOneIssuer && !dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         // this wave's pieces of A(t+1) (and its stores) retired before the barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(t, 8);
@@ -396,7 +427,7 @@ int launch_res(const ResArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_res");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132)
+    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132) SGP_ABL(64) SGP_ABL(72)
 #undef SGP_ABL
 #endif
     auto kern = spmm_res<HALO, NW, G, D, PASSES>;

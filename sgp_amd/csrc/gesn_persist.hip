@@ -82,7 +82,8 @@ __device__ __forceinline__ void st4_agent(float* p, f32x4 v) {
 
 // Two levels: workgroup b arrives at group counter b % kBarGroups (own cache line each); the last
 // arrival of a group bumps the top counter, which everybody polls.  One counter for all ~200
-// workgroups serialises their read-modify-writes at the coherence point (6.5 us per tick measured).
+// workgroups serialises their read-modify-writes at the coherence point (6.5 us per tick measured);
+// per-workgroup flags polled by one wave (4 coalesced loads per poll) came out the same as this (16.6 vs 16.0 us per tick).
 constexpr int kBarGroups = 16;
 constexpr int kBarWords = 16 + 16 * kBarGroups;   // [0] top, [1] failure flag, [16 + 16 g] group g
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned round, int* lds_flag) {
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
     // in one batch) -- kept "resident" there, hipcc spilled it to scratch and reloaded it one value per
     // MFMA (8 us per tick).
     constexpr bool KEEP_W = KSB <= 4;
-    const f32x4* wfrag = reinterpret_cast<const f32x4*>(a.wpk) +
-        ((long long)(layer * (2 * R / 16) + min(cg * 4 + ct, 2 * R / 16 - 1)) * 4 + ks) * KSB * 64 + lane;
+    const unsigned wfrag_off = (unsigned)(((layer * (2 * R / 16) + min(cg * 4 + ct, 2 * R / 16 - 1)) * 4 + ks) * KSB * 64 + lane);
+    const f32x4* wfrag = reinterpret_cast<const f32x4*>(a.wpk) + wfrag_off;
     f32x4 wkeep[KEEP_W ? KSB : 1];
     if constexpr (KEEP_W) {
 #pragma unroll
@@ -204,10 +205,16 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
     auto gemm = [&](int parity) {
         if (has_cols) {
             f32x4 wreg[KSB];
+            // (the fragment's address is re-made from one 32-bit offset here: kept as ready-made 64-bit
+            // pointers across the tick loop -- one per 4 KiB of immediate range -- they cost the registers
+            // that decide between spilling and not)
+            unsigned wo = wfrag_off;
+            asm volatile("" : "+v"(wo));
+            const f32x4* wf = reinterpret_cast<const f32x4*>(a.wpk) + wo;
 #pragma unroll
             for (int b = 0; b < KSB; ++b) {
                 if constexpr (KEEP_W) wreg[b] = wkeep[b];
-                else wreg[b] = wfrag[b * 64];
+                else wreg[b] = wf[b * 64];
             }
             for (int r = 0; r < RT; ++r) {
                 f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
     // update role: a wave serves TWO nodes at a time, one per 32-lane half (flat index 2 (wave + 16 q)
     // + half over the RT x 16 nodes); lane l32 of a half owns features 4 (32 s + l32) .. + 3, s < S
     constexpr int S = KSB / 2;                                    // 16-byte slices per lane (R <= 128 S)
-    constexpr int EB = KSB <= 2 ? 8 : (KSB == 4 ? 6 : 3);   // edges requested per round trip (VGPR budget)
+    constexpr int EB = KSB <= 2 ? 8 : (KSB == 4 ? 6 : 4);   // edges requested per round trip (VGPR budget)
     const int half = lane >> 5, l32 = lane & 31;
     const int n_ticks = a.tc + a.L - 1;
     for (int tick = 0; tick < n_ticks; ++tick) {
@@ -264,7 +271,6 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
                 const int idx = 2 * (wave + 16 * q) + half;       // my node among the workgroup's
                 const int n = node_lo + idx;
                 const bool live = idx < RT * 16 && n < a.N;
-                float* hrow = hb + idx * RP;
                 const float* p0row = a.p0 + ((long long)t * a.N + n) * R;
                 const float* pbase = c_below + rd * plane;                    // wave-uniform
                 const unsigned poff = (unsigned)((n * 2 * R + R + 4 * l32) * 4);
@@ -344,6 +350,7 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
                     for (int off = 16; off > 0; off >>= 1) ss += __shfl_xor(ss, off);   // within my half
                     inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
                 }
+                float* hrow = hb + idx * RP;
                 float* orow = a.out + (long long)t * a.oss + (long long)n * a.ors + (long long)layer * R;
 #pragma unroll
                 for (int s2 = 0; s2 < S; ++s2) {

@@ -164,6 +164,27 @@ def test_tile_plan_small_sparse_graph():
     _check_plan(op, plan)
 
 
+@pytest.mark.parametrize("n,e,rows,tiles", [(207, 1515, 207, 1), (325, 2369, 325, 1), (700, 4900, 64, None)])
+def test_operator_picks_tall_tiles_for_small_sparse_graphs(n, e, rows, tiles):
+    """Traffic-sized sparse graphs are planned as ONE tile (the VALU kernel stages the whole slab once
+    per step); the 64-row plan stays available for the kernels that need it; a 700-node random graph
+    has no tall tile that fits the stage."""
+    ei, ew = synthetic.sparse_traffic_graph(n, e, seed=1)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    limits = dict(max_union=448, max_tile_rows=64, max_row_edges=128)     # what hip.tiled_limits gives
+    plan = op.tile_plan(64, torch.device("cpu"), limits=limits)
+    assert plan is not None and plan.tile_rows == rows
+    if tiles is not None:
+        assert plan.n_tiles == tiles and plan.gw is None
+        _check_plan(op, plan)
+        # LDS budget of sgp_spmm_tiled_f32's tall form: staged rows (whole passes of 64) + 6 B per edge slot
+        rpg = 4 if plan.tile_rows <= 256 else 6
+        nb = 1 if plan.max_row_edges <= 16 else 2
+        assert (plan.max_union + 63) // 64 * 64 * 256 + rpg * 64 * nb * 16 * 6 <= 160 * 1024
+    std = op.tile_plan(64, torch.device("cpu"), limits=limits, tall=False)
+    assert std.tile_rows <= 64 and std.gw is not None
+
+
 # ------------------------------------------------------------------ weights / API surface
 @pytest.mark.parametrize("name", [f for f in golden_files("g4_seed") if "gesn" not in f])
 def test_seed_reproduces_reference_weights(name):

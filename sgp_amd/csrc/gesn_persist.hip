@@ -14,16 +14,16 @@
 //  * a workgroup owns (layer l, a group of 64 output columns of [W_hh,l ; W_ih,l+1], RT row tiles of
 //    16 nodes) for the whole launch: its slice of the weights lives in REGISTERS as MFMA operands
 //    (R / 16 VGPRs per wave), its nodes' states and adjacency rows in LDS;
-//  * per tick: "update" -- one wave per node gathers the neighbours' z rows, adds p, applies
-//    activation + leak, writes h' to LDS (every column group of a row tile repeats this: it needs
-//    the whole h' row as its GEMM operand, and repeating a 16-node gather is cheaper than another
-//    barrier) -- then "GEMM" -- C[16 nodes, 64 cols] = h' W^T on v_mfma_f32_16x16x4_f32, K split
-//    over the 4 wave quarters and reduced through LDS -- into the tick's parity of a double buffer
-//    that holds z_l for the next step and p_{l+1} for this one.
+//  * per tick: "update" -- a wave serves two nodes (one per 32-lane half): gathers the neighbours' z
+//    rows, adds p, applies activation + leak, writes h' to LDS (every column group of a row tile
+//    repeats this: it needs the whole h' row as its GEMM operand, and repeating a 32-node gather is
+//    cheaper than another barrier) -- then "GEMM" -- C[16 nodes, 64 cols] = h' W^T on
+//    v_mfma_f32_16x16x4_f32, K split over the 4 wave quarters and reduced through LDS -- into the
+//    tick's parity of a double buffer that holds z_l for the next step and p_{l+1} for this one.
 // The first GEMM of a launch runs on the initial states with the same code, so a sequence cut into
 // several calls is bit-identical to one call.  The XCDs' L2s are not coherent with each other: the C
-// buffers are accessed with agent-scope atomics only (see ld_agent), everything static stays in
-// registers / LDS.
+// buffers are read and written with `sc1` (agent-scope) accesses only (ld4_agent / st4_agent),
+// everything static stays in registers / LDS.
 // A barrier that does not complete (it cannot, under a cooperative launch) raises a flag after ~1 s
 // instead of hanging the device; the host falls back to gesn.hip's path on any launch problem.
 #include "common.h"
@@ -55,17 +55,13 @@ struct PArgs {
     int n_cg[kMaxLayers];                  // column groups (64 wide) of layer l
 };
 
-// Everything the workgroups exchange (the C buffers) is read and written with agent-scope atomics
-// (global_load / global_store ... sc1: coherent across the XCDs' L2s on their own), so the barrier
-// needs no L2 write-back / invalidate: with __threadfence() on both sides (buffer_wbl2 sc1 +
-// buffer_inv sc1 from every wave) a tick cost 160 us, 2.5x the six-launch step it replaces.
-__device__ __forceinline__ float ld_agent(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// 16-byte form: no 128-bit atomic exists, so the sc1 load is issued from inline asm; the caller waits
-// (s_waitcnt vmcnt) before it reads `r`.
-// (scalar base + one 32-bit lane offset + immediate: one address VGPR per row instead of two per
-// load -- with 64-bit lane addresses the weight fragment was spilled to scratch)
+// Everything the workgroups exchange (the C buffers) is read and written at agent scope
+// (global_load / global_store ... sc1 -- what an agent-scope atomic compiles to: coherent across the
+// XCDs' L2s on its own), so the barrier needs no L2 write-back / invalidate: with __threadfence() on
+// both sides (buffer_wbl2 sc1 + buffer_inv sc1 from every wave) a tick cost 160 us, 2.5x the six-launch
+// step it replaces.  16-byte form (no 128-bit atomic exists): issued from inline asm, the caller waits
+// (s_waitcnt vmcnt) before it reads `r`; scalar base + one 32-bit lane offset + immediate = one
+// address VGPR per row instead of two per load.
 template <int IMM>
 __device__ __forceinline__ void ld4_agent(f32x4& r, const float* sbase, unsigned voff) {
     asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3 sc1" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");

@@ -6,7 +6,7 @@ Default workload = the target line of BASELINE.json's north_star / BASELINE.md 3
 N = 100 000 nodes, 100-NN geometric graph (Morton order), T = 1024, F_in = 64, reservoir 64 x 1,
 K = 4  ->  D_out = 320, 131 GB of output, 157 GB resident.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c1|c2|c3|c4|c5|small]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload target|c1|c2|c3|c4|c5|small|random]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the SAME graph is node-partitioned across the ranks (strong scaling): reservoir
@@ -46,8 +46,13 @@ WORKLOADS = {
     # overwritten by the next one: benchmark mode "encode and discard")
     "c5": dict(N=100000, T=1024, F=128, R=256, L=1, K=5, bidir=False, glob=False, graph="knn100",
                t_chunk=256),
+    # SURVEY.md 8d's adversarial secondary graph ("random sparse A"): 100 uniformly random columns per
+    # row, no locality to tile for -> the generic CSR kernel gathers through L2 / Infinity Cache
+    "random": dict(N=100000, T=256, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="random100"),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+GRAPH_NAMES = {"knn100": "100-NN geometric graph (Morton order)", "traffic": "traffic-like sparse graph",
+               "random100": "100 uniformly random columns per row (no locality)"}
 
 
 def profiled_traffic(workload, kernel):
@@ -67,6 +72,8 @@ def profiled_traffic(workload, kernel):
 def build_graph(w):
     if w["graph"] == "knn100":
         ei, ew, _ = synthetic.knn_graph(w["N"], 100, seed=1)
+    elif w["graph"] == "random100":
+        ei, ew = synthetic.random_graph(w["N"], 100, seed=1)
     else:
         ei, ew = synthetic.sparse_traffic_graph(w["N"], 1515 if w["N"] < 300 else 2369, seed=1)
     return ei, ew
@@ -295,7 +302,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={N} nodes, T={T} steps, F_in={F}, "
                                    f"reservoir {R}x{L}, K={K}, "
-                                   f"{'100-NN geometric graph (Morton order)' if w['graph'] == 'knn100' else 'traffic-like sparse graph'}"
+                                   f"{GRAPH_NAMES[w['graph']]}"
                                    f"{', bidirectional' if w['bidir'] else ''}"
                                    f"{', global_attr' if w['glob'] else ''}",
                        "nnz": nnz, "d_out": enc.output_size, "t_chunk": tc,

@@ -9,7 +9,7 @@
 // another read -- on gfx950 every VALU instruction and every VGPR write of an LDS return takes
 // issue time from the fp32 matrix pipe (tools/ubench/res_loop2.hip: 42-46 cycles per 32 cycles of
 // MFMAs, fold and store included, against ~55 for the spmm_pipe body).
-// Registers hold the first SH super-steps of either range of a group (96 % of the ranges of the
+// Registers hold the first SH super-steps of either range of a group (99 % of the ranges of the
 // 100-NN target graph are shorter); what lies beyond is walked from an LDS copy of the stream the
 // way spmm_pipe does (not software-pipelined: those groups mix rows of two distant clusters and
 // are the slowest of their tile in any case).
@@ -44,8 +44,11 @@ struct ResArgs {
     unsigned* dbg;                         // timeline stamps (ablation builds only)
 };
 
-constexpr int SH = 20;                     // super-steps per range held in registers (80 columns)
-constexpr int WH = (SH + 3) / 4;           // weight registers per range
+// Super-steps per range held in registers: 24 (96 columns; 126 VGPRs with the halo source) / 28 when
+// there is no halo pointer to carry.  On the 100-NN target graph 1.0 % / 0.0 % of the ranges are
+// longer (17 % / 1 % of the tiles have one); with 20, 1.8 % / 30 % -- and a tile waits for its
+// overflow walk, which is not software-pipelined: 12.7 -> 12.45 ms per 512 steps for 20 -> 24.
+template <bool HALO> struct ResidentSteps { static constexpr int value = HALO ? 24 : 28; };
 
 // cache policy bits of the staging reads (experiment builds: -DSGP_DMA_MOD='" sc0"' etc.)
 #ifndef SGP_DMA_MOD
@@ -68,6 +71,8 @@ __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off)
 template <bool HALO, int NW, int G, int D, int PASSES, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    constexpr int SH = (G == 1) ? ResidentSteps<HALO>::value : 20;   // (two groups per wave: 20, the register budget of cfg 1)
+    constexpr int WH = (SH + 3) / 4;                      // weight registers per range
     constexpr int GT = NW * G;
     constexpr int RPP = NW * 4;                           // staged rows per DMA pass
 
@@ -149,7 +154,21 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
     constexpr int kStageBytes = PASSES * RPP * 256;
     const int tile_q0 = a.gptr[tile * (2 * GT)], tile_q1 = a.gptr[tile * (2 * GT) + 2 * GT];
     const int tile_quads = tile_q1 - tile_q0;
-    if constexpr ((ABL & 8) == 0) {
+    // (only a tile that HAS a longer range: 1 % of the 64-row tiles of the 100-NN graph at SH = 28)
+    // (voted through the first word of the still unused stage: __syncthreads_or would add a static
+    // LDS word to the 160 KB of dynamic LDS)
+#ifndef SGP_RES_NO_VOTE
+    int* vote = reinterpret_cast<int*>(lds);
+    if (tid == 0) *vote = 0;
+    __syncthreads();
+    if (a.gsup[tile * (2 * GT) + (tid % (2 * GT))] > SH) *vote = 1;
+    __syncthreads();
+    const bool tile_has_long_range = *vote != 0;
+    __syncthreads();
+#else
+    const bool tile_has_long_range = true;
+#endif
+    if ((ABL & 8) == 0 && tile_has_long_range) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.gw) + (long long)tile_q0 * 16;
         f32x4* dst = reinterpret_cast<f32x4*>(lds + kStageBytes);
         for (int i = tid; i < tile_quads * 16; i += NW * 64) dst[i] = src[i];

@@ -88,6 +88,10 @@ int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
  *   eval[e]               = weight
  * max_union = largest per-tile list length, max_row_edges = largest padded per-row
  * edge count (host-side facts about the plan; they select the kernel variant).
+ * Tiles of more than 128 rows (up to sgp_spmm_tiled_max_tile_rows() = 384; rows with at most 32
+ * edges) take the tall form: the edge records live in LDS behind the stage, which must then hold
+ * ceil(max_union / 64) * 16 KiB + 6 bytes per padded edge slot of 256 / 384 rows within 160 KiB
+ * (small sparse graphs as ONE tile: every source row is staged once per step).
  * Returns SGP_EUNSUP if the plan exceeds the limits reported below.
  */
 int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,

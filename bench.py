@@ -246,26 +246,12 @@ def main():
             state.zero_()
         for t0 in range(0, T, tc):
             xs, oc = x[t0:t0 + tc], out[:min(tc, T - t0)]
-            enc.reservoir.encode_into(xs, oc[:, :, :d_h], state)
             if spatial is None:
-                # hops launched one by one so each can be bracketed by HIP events on its stream
-                for d, op in enumerate(ops):
-                    src = oc[:, :, :d_h]
-                    for h in range(K):
-                        s = 1 + d * K + h
-                        dst = oc[:, :, s * d_h:(s + 1) * d_h]
-                        if timed:
-                            a, b = hip.Event(), hip.Event()
-                            a.record()
-                        op.propagate(src, dst)
-                        if timed:
-                            b.record()
-                            hop_ms.append((a, b))
-                        src = dst
-                if w["glob"]:
-                    p = enc.sgp_encoder.num_blocks() - 1
-                    hip.node_mean_bcast(oc[:, :, :d_h], oc[:, :, p * d_h:(p + 1) * d_h])
+                # the product path (reservoir, hops, global mean; small graphs: hops of one time piece
+                # under the reservoir of the next); every hop launch bracketed by HIP events on its stream
+                enc.encode_device(xs, ops, out=oc, state=state, timeline=hop_ms if timed else None)
             else:
+                enc.reservoir.encode_into(xs, oc[:, :, :d_h], state)
                 spatial.timeline = timeline if timed else None
                 spatial.encode_into(oc, d_h)
 
@@ -275,8 +261,10 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        step(False)
+        step(True)                   # (with the event brackets: their first use grows runtime pools)
     barrier()
+    del hop_ms[:]
+    del timeline[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
@@ -313,15 +301,22 @@ def main():
         }
         if hop_ms:
             per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
-            bts = hop_bytes(N, tc, d_h, nnz)              # one launch covers one time chunk
+            # one launch covers one time chunk -- or, on small graphs, one of the pieces the encoder
+            # cuts it into to run the hops under the reservoir (SGPEncoder.encode_device)
+            n_chunks = T // tc if T % tc == 0 else T // tc + 1
+            pieces = max(1, round(len(hop_ms) / (args.steps * n_chunks * K * len(ops))))
+            bts = hop_bytes(N, tc / pieces, d_h, nnz)
             achieved = bts / (per_launch * 1e-3) / 1e9
             kernel = getattr(ops[0], "last_kernel", "?")
             traffic, source = profiled_traffic(args.workload, kernel)
+            if traffic is not None and pieces > 1:
+                traffic /= pieces                          # (profiled per launch of the same size)
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": source,
                                "kernel": kernel,
-                               "ms_per_launch": per_launch, "algorithmic_bytes": bts}
+                               "ms_per_launch": per_launch, "algorithmic_bytes": bts,
+                               "launches_per_hop": pieces}
         elif timeline:
             # rank 0's GPU: a hop of the local block = its launches over the time chunks; the
             # exchange of a hop = gather + all_to_all on the communication stream

@@ -120,19 +120,61 @@ class SGPEncoder(nn.Module):
             undirected=undirected,
             add_self_loops=add_self_loops,
             global_attr=global_attr)
+        self._side_streams = {}
 
     @property
     def output_size(self):
         return self.sgp_encoder.num_blocks() * self.reservoir.output_size
 
-    def encode_device(self, x, ops, out=None):
-        """x[T, N, F] CUDA float32 -> out[T, N, D_out] on the same device."""
+    # Small graphs: the reservoir is a serial chain of T steps on ceil(N / 16) CUs (PEMS-BAY: 21 of
+    # 256) and the hops are bandwidth-bound on all of them.  Up to `overlap_tiles` node tiles, and when
+    # the hops are worth it (their estimated time >= a quarter of the chain's), the time axis is cut
+    # into `overlap_chunks` pieces and the hops (+ global mean) of piece i run on a second stream under
+    # the reservoir of piece i + 1 (state carried on the device: bit-identical to one pass).
+    # PEMS-BAY shape: 107 -> 93 ms per pass (the chain runs ~10 % slower beside the hops); METR-LA
+    # shape (K = 2, hops = 7 % of the pass) keeps one piece: cut in 8 it took 30 ms instead of 22.
+    overlap_tiles = 128
+    overlap_chunks = 8
+
+    def _overlap_pieces(self, T, N):
+        if (N + 15) // 16 > self.overlap_tiles or T < 64 * self.overlap_chunks:
+            return 1
+        L, R = len(self.reservoir.reservoir_layers), self.reservoir.hidden_size
+        chain_us = (0.3 + 7.3e-5 * R * R) * L                 # per step: 0.6 us at R = 64, 1.5 at 128 (measured)
+        hop_us = (self.sgp_encoder.num_blocks() - 1) * N * L * R * 8 / 4e6   # bytes of the hop blocks at ~4 TB/s
+        return self.overlap_chunks if hop_us >= 0.25 * chain_us else 1
+
+    def encode_device(self, x, ops, out=None, state=None, timeline=None):
+        """x[T, N, F] CUDA float32 -> out[T, N, D_out] on the same device.  ``state`` [L, N, R]:
+        reservoir state carried across calls (updated in place); ``timeline``: see
+        ``sgp_preprocessing.propagate_into``."""
         T, N, _ = x.shape
         d_h = self.reservoir.output_size
         if out is None:
             out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
-        self.reservoir.encode_into(x, out[:, :, :d_h])
-        self.sgp_encoder.encode_into(out, d_h, ops)
+        chunks = self._overlap_pieces(T, N)
+        if chunks <= 1:
+            self.reservoir.encode_into(x, out[:, :, :d_h], state)
+            self.sgp_encoder.encode_into(out, d_h, ops, timeline)
+            return out
+        if state is None:
+            state = torch.zeros(len(self.reservoir.reservoir_layers), N, self.reservoir.hidden_size,
+                                dtype=torch.float32, device=x.device)
+        main = torch.cuda.current_stream(x.device)
+        key = str(x.device)
+        if key not in self._side_streams:
+            self._side_streams[key] = torch.cuda.Stream(device=x.device)
+        side = self._side_streams[key]
+        side.wait_stream(main)                                  # (out / earlier work of the caller)
+        for j in range(chunks):
+            t0, t1 = T * j // chunks, T * (j + 1) // chunks
+            self.reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ready)
+                self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline)
+        main.wait_stream(side)
         return out
 
     # Device-memory budget for one pass (bytes); None = 80 % of what is free right now.  Host
@@ -248,8 +290,7 @@ class SGPEncoder(nn.Module):
                     drain(i - nbuf)                              # (no-op on the direct path)
                     main.wait_event(ev_d2h[s])                   # buf[s] has been copied out
                 oc = buf[s][:n]
-                self.reservoir.encode_into(xin[s][:n], oc[:, :, :d_h], state)
-                self.sgp_encoder.encode_into(oc, d_h, ops)
+                self.encode_device(xin[s][:n], ops, out=oc, state=state)
                 ev_done[s].record(main)
                 send_out(i)
                 used[s] = True

@@ -33,11 +33,11 @@ class SGPSpatialEncoder(nn.Module):
                                  add_self_loops=self.add_self_loops,
                                  bidirectional=self.bidirectional)
 
-    def encode_into(self, out, feat, ops):
+    def encode_into(self, out, feat, ops, timeline=None):
         """Device path.  ``out[B, N, P * feat]`` with slot 0 already filled: run the hops
         and the global-mean block in place (sgp_spatial_encoder.py:22-35 without the
         ``torch.cat``)."""
-        propagate_into(out, feat, ops, self.receptive_field)
+        propagate_into(out, feat, ops, self.receptive_field, timeline)
         if self.global_attr:          # :32-34
             p = self.num_blocks() - 1
             hip.node_mean_bcast(out[:, :, :feat], out[:, :, p * feat:(p + 1) * feat])

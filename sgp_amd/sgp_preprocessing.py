@@ -70,16 +70,25 @@ def spatial_operators(edge_index, edge_weight, num_nodes, undirected=False,
     return ops
 
 
-def propagate_into(out, feat, ops, k):
+def propagate_into(out, feat, ops, k, timeline=None):
     """Fill hop slots of ``out[B, N, (1 + len(ops) * k) * feat]`` in place: slot 0 must
     already hold x; slot 1 + d*k + (h-1) receives ops[d]^h x.  No concatenation and no
-    temporaries: every hop reads one slot and writes the next."""
+    temporaries: every hop reads one slot and writes the next.  ``timeline``: a list that
+    receives one (start, end) pair of ``hip.Event`` per hop launch, recorded on the stream the
+    hop runs on (bench.py's roofline timing)."""
     for d, op in enumerate(ops):
         src = out[:, :, 0:feat]
         for h in range(k):
             s = 1 + d * k + h
             dst = out[:, :, s * feat:(s + 1) * feat]
+            if timeline is not None:
+                from . import hip
+                a, b = hip.Event(), hip.Event()
+                a.record()
             op.propagate(src, dst)
+            if timeline is not None:
+                b.record()
+                timeline.append((a, b))
             src = dst
     return out
 

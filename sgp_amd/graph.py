@@ -148,8 +148,6 @@ class ShiftOperator:
         plan with <= 64-row tiles that every LDS-staged kernel accepts, even where a tall-tile plan
         (VALU kernel only) exists."""
         key = (feat % 64 == 0, str(device))
-        if not tall and key in self._plans and (key, "std") in self._plans:
-            return self._plans[(key, "std")]
         if key not in self._plans:
             plan = None
             if feat % 64 == 0 and self.nnz() > 0:
@@ -195,6 +193,8 @@ class ShiftOperator:
                 if plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
+        if not tall and (key, "std") in self._plans:     # also on the call that built both variants
+            return self._plans[(key, "std")]
         return self._plans[key]
 
     def block_plan(self, feat, device):

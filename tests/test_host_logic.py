@@ -183,6 +183,12 @@ def test_operator_picks_tall_tiles_for_small_sparse_graphs(n, e, rows, tiles):
         assert (plan.max_union + 63) // 64 * 64 * 256 + rpg * 64 * nb * 16 * 6 <= 160 * 1024
     std = op.tile_plan(64, torch.device("cpu"), limits=limits, tall=False)
     assert std.tile_rows <= 64 and std.gw is not None
+    # the FIRST call of a fresh operator asking for the 64-row plan gets it too (round-2 advisor finding:
+    # it used to return the tall plan it had just built)
+    op2 = graph.ShiftOperator.from_edges(ei, ew, n)
+    first = op2.tile_plan(64, torch.device("cpu"), limits=limits, tall=False)
+    assert first.tile_rows <= 64 and first.gw is not None
+    assert op2.tile_plan(64, torch.device("cpu"), limits=limits).tile_rows == rows
 
 
 # ------------------------------------------------------------------ weights / API surface

@@ -183,6 +183,36 @@ int32_t sgp_spmm_res_max_union(void);
 int32_t sgp_spmm_res_max_quads(void);
 int sgp_spmm_res_tune(int32_t cfg);
 
+/* Mixed dense / sparse form of the row-group product (lib/sgp_preprocessing.py:200-203, `x = adj @ x`
+ * per hop; plan: sgp_amd/mixplan.py).  Tiles, staged rows, two-phase LDS-DMA staging and the
+ * 4-row-group stream (uptr .. rowmap, gptr .. gw) are those of sgp_spmm_res_f32, but the 16 groups of
+ * a tile form 4 blocks of 16 rows (tile slot = 16 block + 4 group + row), and the columns shared by
+ * (nearly) all groups of a block are taken out of the group streams and multiplied by
+ * v_mfma_f32_16x16x4_f32 instead (16 rows x 4 columns x 16 features per instruction):
+ *   dptr[2 * 4 * n_tiles + 1]   first dense instruction of (tile, block, segment)
+ *   didx[n_dense][4]            LDS byte offsets (staged row * 256) of the instruction's 4 columns
+ *   dw[n_dense][64]             its A operand in lane order: lane 16 k + i = weight of (row i of the
+ *                               block, column k), 0 where the row does not use the column
+ * max_dense = longest (block, segment) list, at most sgp_spmm_mix_max_dense(halo != 0) (the lists
+ * live in registers).  Wave w of a workgroup owns sparse group w and the dense part of block w / 4
+ * for the feature quarter w % 4; dense sums reach the storing wave through a 16 KB LDS slab.
+ * Arithmetic: exact fp32 FMAs; a row's sum is (sparse part, k order of its group stream) + (dense
+ * part, k order of the block's list) -- another summation order than sgp_spmm_res_f32, same values
+ * to rounding.  X / X_halo / Y as in sgp_spmm_tiled_f32. */
+int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
+                     const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
+                     const int32_t* rowmap,
+                     const int32_t* dptr, const int32_t* didx, const float* dw,
+                     int32_t n_tiles, int32_t max_union, int32_t max_dense,
+                     const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                     const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
+                     int32_t n_own,
+                     float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                     int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                     sgp_stream_t stream);
+int32_t sgp_spmm_mix_max_union(void);
+int32_t sgp_spmm_mix_max_dense(int32_t halo);
+
 /* Row-block form of the row-group product (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/rowblock.py).  A workgroup of sgp_spmm_blk_waves() = 8 waves owns a tile of up to 128
  * rows; a wave owns FOUR 4-row groups, one per 16-lane class of v_mfma_f32_4x4x1_16b_f32, and

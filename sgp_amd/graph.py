@@ -222,6 +222,34 @@ class ShiftOperator:
             self._plans[key] = plan
         return self._plans[key]
 
+    def mix_plan(self, feat, device, strict=True):
+        """Mixed dense / sparse plan (``sgp_amd.mixplan``, kernel ``sgp_spmm_mix_f32``) on the tiles and
+        row groups of the 64-row plan, or None: needs feature widths that are multiples of 64, a
+        two-phase stream, and blocks of 16 rows that share enough columns for the dense form to pay
+        (k-NN-like graphs; ``SGP_MIX_MIN_SHARE``, default 0.25 of the (group, column) pairs)."""
+        key = ("mix", feat % 64 == 0, str(device), bool(strict))
+        if key not in self._plans:
+            plan = None
+            base = self.tile_plan(feat, device, tall=False)
+            if base is not None and base.pipe is not None and (base.group_fill >= 0.5 or not strict):
+                from . import hip, mixplan
+                lib = hip.load()
+                order = None
+                if base.reordered:
+                    order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
+                plan = mixplan.build_mix_plan(
+                    self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, base,
+                    thr=int(os.environ.get("SGP_MIX_THR", "4")),
+                    dh=lib.sgp_spmm_mix_max_dense(int(self.num_cols > self.num_nodes)), order=order)
+                min_share = float(os.environ.get("SGP_MIX_MIN_SHARE", "0.25")) if strict else -1.0
+                if plan is not None and (plan.dense_share < min_share
+                                         or plan.max_union > lib.sgp_spmm_mix_max_union()):
+                    plan = None
+                if plan is not None:
+                    plan = plan.to(device)
+            self._plans[key] = plan
+        return self._plans[key]
+
     def propagate(self, x, y, force=None, halo=None):
         """y[b] = A [x[b]; halo[b]] for strided [B, N, F] CUDA views (no allocation).
         ``halo[B, num_cols - num_nodes, F]`` (any strides) supplies the columns past the
@@ -238,6 +266,14 @@ class ShiftOperator:
         if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
             raise ValueError("halo batch / feature size differs from x")
         plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
+        halo_fits = not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30)
+        # mixed dense / sparse kernel: SGP_SPMM_DEFAULT=mix makes it the first choice where it has a plan
+        if force is None and plan is not None and halo_fits and os.environ.get("SGP_SPMM_DEFAULT", "") == "mix":
+            mplan = self.mix_plan(x.shape[2], x.device)
+            if mplan is not None:
+                self.last_kernel = "spmm_mix"
+                hip.spmm_mix(mplan, x, y, halo, self.num_nodes)
+                return y
         # row-block kernel: on request only (measured on the target graph: better compute, 10.3 vs
         # 10.7 ms per 512 steps without staging, but its 128-row tiles halve the number of time
         # steps of an XCD's working set that fit the L2 -- 14.9 vs 12.8 ms with staging)
@@ -250,6 +286,15 @@ class ShiftOperator:
                 return y
         if force == "blk":
             raise NotImplementedError("no row-block plan for this graph / feature width")
+        if force == "mix" and plan is not None and \
+                not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30):
+            mplan = self.mix_plan(x.shape[2], x.device, strict=False)
+            if mplan is not None:
+                self.last_kernel = "spmm_mix"
+                hip.spmm_mix(mplan, x, y, halo, self.num_nodes)
+                return y
+        if force == "mix":
+            raise NotImplementedError("no mixed dense / sparse plan for this graph / feature width")
         if force in ("tiled", "mfma", "pipe", "res") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
         if force == "mfma" and (plan is None or plan.gw is None):

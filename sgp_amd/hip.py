@@ -59,6 +59,15 @@ SIGNATURES = {
     "sgp_spmm_res_max_union": (c_i32, []),
     "sgp_spmm_res_max_quads": (c_i32, []),
     "sgp_spmm_res_tune": (ctypes.c_int, [c_i32]),
+    "sgp_spmm_mix_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                        c_p, c_p, c_p,
+                                        c_i32, c_i32, c_i32,
+                                        c_p, c_i64, c_i64,
+                                        c_p, c_i64, c_i64, c_i32,
+                                        c_p, c_i64, c_i64,
+                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_mix_max_union": (c_i32, []),
+    "sgp_spmm_mix_max_dense": (c_i32, [c_i32]),
     "sgp_spmm_blk_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                         c_i32, c_i32, c_i32,
                                         c_p, c_i64, c_i64,
@@ -316,6 +325,28 @@ def spmm_res(plan, x, y, halo=None, n_own=None):
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_res_f32")
+
+
+@_on_device
+def spmm_mix(plan, x, y, halo=None, n_own=None):
+    """Mixed dense (16x16x4) / sparse (4x4x1) row-group product (plan: sgp_amd.mixplan.MixPlan on the
+    device of ``x``)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
+    _check(lib.sgp_spmm_mix_f32(
+        plan.uptr.data_ptr(), plan.ucol.data_ptr(), plan.usplit.data_ptr(),
+        plan.gptr.data_ptr(), plan.gsup.data_ptr(), plan.gidx.data_ptr(), plan.gw.data_ptr(),
+        plan.rowmap.data_ptr(), plan.dptr.data_ptr(), plan.didx.data_ptr(), plan.dw.data_ptr(),
+        plan.n_tiles, plan.max_union, plan.max_dense,
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
+        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
+        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mix_f32")
 
 
 @_on_device

@@ -236,6 +236,8 @@ def main():
     state = torch.zeros(L, n_own, R, device=dev) if tc < T else None
     for o in local_ops:                                     # plans + device CSR built once
         o.tile_plan(d_h, dev)
+        if os.environ.get("SGP_SPMM_DEFAULT", "mix") == "mix":
+            o.mix_plan(d_h, dev)
         o.device_csr(dev)
 
     hop_ms = []

@@ -87,7 +87,7 @@ template <int SH, int DH> struct Regs {
 // SH / DH: resident super-steps / dense instructions per phase; D / DD: operand rings.
 // ABL (ablation builds): bit0 no staging DMA, bit1 no dense instructions, bit2 no sparse super-steps,
 // bit7 per-wave s_memtime timeline of one workgroup.
-template <bool HALO, int SH, int DH, int D, int DD, int ABL = 0>
+template <bool HALO, int SH, int DH, int D, int DD, bool ILV, int ABL = 0>
 __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     using R = Regs<SH, DH>;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     const int tile_q0 = a.gptr[tile * (2 * NW)];
     const int rb = wave >> 2, fq = wave & 3;
     unsigned F[2][NF];
-    int n[2], nl[2], nd[2], qrel[2];
+    int n[2], nl[2], nd[2], kk[2], qrel[2];
     {
         const int grp = (tile * NW + wave) * 2;
         const int q0 = __builtin_amdgcn_readfirstlane(a.gptr[grp]);
@@ -195,6 +195,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
             const int free_q = (2 * DH - 2 * nd[ph]) / 5;
             const int need_q = (n[ph] + D - SH + 3) >> 2;
             nl[ph] = n[ph] <= SH ? n[ph] : (need_q <= free_q ? n[ph] : SH + 4 * max(free_q - 1, 0));
+            kk[ph] = max(nd[ph], nl[ph]);                 // iterations of the interleaved loop
             // resident part: weights of quads 0 .. WH-1, addresses of super-steps 0 .. SH-1
 #pragma unroll
             for (int p = 0; p < WH; ++p)
@@ -393,6 +394,70 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0];     \
     }
 
+    // ---- interleaved form of a phase (ILV): ONE loop in which the wave alternates a 16x16x4 instruction
+    // of its block with a super-step (4 x 4x4x1) of its group,
+    //     [i < nd:  wait N(i) | mfma 16x16x4]  issue N(i + DD)  [i < nl:  wait S(i) | 4 mfma 4x4x1]  issue S(i + D)
+    // so that the 32 matrix-pipe cycles of either cover the LDS latency of the other's operands -- a
+    // wave whose 4x4x1 super-steps run back to back waits ~100 cycles per super-step for its reads
+    // (3 in flight against ~300 cycles of loaded LDS latency), and with two of a SIMD's four waves
+    // parked at the barrier nobody fills the gaps.  Only the MFMAs and their waits are conditional; the
+    // READS of the first DH iterations are issued whatever nd and nl are (past a list's end they fetch
+    // a valid address for nothing), so the issue order is static and every count exact:
+    //   issued before iteration i: P0 + a(i) + b(i), P0 = D + DD, a(i) = min(i, DH - DD) dense refills,
+    //   b(i) = min(i, SH - D) sparse refills; N(m) sits at D + m (m < DD) or P0 + a(j) + b(j), j = m - DD;
+    //   S(s) at s (s < D) or P0 + a(j) + b(j) + [j < DH - DD], j = s - D.
+    // Past iteration SH - D the sparse refills depend on the range using its extension quads; the dense
+    // reads are over by then (static_assert), and the counts of the plain form apply.
+    static_assert(!ILV || (DH + D <= SH && DH <= SH - 2 * D + 1 + DD), "interleaved part must stay inside the resident super-steps");
+#define I_A(I_) ((I_) < (DH - DD) ? (I_) : (DH - DD))
+#define I_B(I_) ((I_) < (SH - D) ? (I_) : (SH - D))
+#define I_POSN(M_) ((M_) < DD ? D + (M_) : D + DD + I_A((M_) - DD) + I_B((M_) - DD))
+#define I_POSS(S_) ((S_) < D ? (S_) : D + DD + I_A((S_) - D) + I_B((S_) - D) + (((S_) - D) < (DH - DD) ? 1 : 0))
+#define W_IDENSE(I_) (D + DD + I_A(I_) + I_B(I_) - I_POSN(I_) - 1)
+#define W_ISPARSE(I_) ((I_) + D - 1 >= SH ? W_TAIL(I_) : (D + DD + I_A(I_) + I_B(I_) + ((I_) < (DH - DD) ? 1 : 0) - I_POSS(I_) - 1))
+#define SGP_DENSE_MFMA(P_, M_)                                                                     \
+    if ((P_) == 0 && (M_) == 0) {                                                                  \
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                      \
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(F[P_][R::dw(M_)]), dring[(M_) % DD], z, 0, 0, 0); \
+    } else {                                                                                       \
+        dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(F[P_][R::dw(M_)]), dring[(M_) % DD], dacc, 0, 0, 0); \
+    }
+#define SGP_PHASE_ILV(P_, PRE_, MID_, POST_)                                                       \
+    { _Pragma("unroll") for (int s = 0; s < D; ++s) SGP_RD(P_, s); }                               \
+    { _Pragma("unroll") for (int m = 0; m < DD; ++m) SGP_DRD(P_, m); }                             \
+    { PRE_ }                                                                                       \
+    if ((P_) == 0) stamp(t, 9);                                                                    \
+    if ((P_) == 0 && nd[P_] == 0) dacc = f32x4{0.f, 0.f, 0.f, 0.f};                                \
+    if ((P_) == 0 && n[P_] == 0) { acc[0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1] = acc[0]; acc[2] = acc[0]; acc[3] = acc[0]; } \
+    if (kk[P_] > 0) {                                                                              \
+        _Pragma("unroll") for (int i = 0; i < SHX; ++i) {                                          \
+            if (i < DH) {                                                                          \
+                if (i < nd[P_]) {                                                                  \
+                    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(dring[i % DD]) : "n"(W_IDENSE(i < DH ? i : 0))); \
+                    SGP_DENSE_MFMA(P_, (i < DH ? i : 0))                                           \
+                }                                                                                  \
+                if (i + DD < DH) SGP_DRD(P_, (i + DD < DH ? i + DD : 0));                          \
+            }                                                                                      \
+            if (i >= DH || i < nl[P_]) {                                                           \
+                asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ring[i % D]) : "n"(W_ISPARSE(i)));     \
+                SGP_SLOT(P_, i, (P_) == 0 && i == 0)                                               \
+            }                                                                                      \
+            if (i + D < SH) { SGP_RD(P_, i + D); }                                                 \
+            else if (i < SH) { if (nl[P_] > SH) SGP_RD(P_, i + D); }                               \
+            else if (i + D < SHX) { SGP_RD(P_, i + D); }                                           \
+            if (i == 2) { MID_ }                                                                   \
+            if (i + 1 == kk[P_]) break;                                                            \
+        }                                                                                          \
+    }                                                                                              \
+    stamp(t, (P_) == 0 ? 10 : 11);                                                                 \
+    if ((P_) == 1) {                                                                               \
+        asm volatile("s_nop 7\n\ts_nop 7\n\tds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:256\n\t" \
+                     "ds_write_b32 %0, %3 offset:512\n\tds_write_b32 %0, %4 offset:768"           \
+                     :: "v"(slab_w), "v"(dacc.x), "v"(dacc.y), "v"(dacc.z), "v"(dacc.w) : "memory"); \
+    }                                                                                              \
+    { POST_ }                                                                                      \
+    if (n[P_] > nl[P_]) overflow(qrel[P_], nl[P_] >> 2, n[P_]);
+
     auto stamp = [&](int t, int point) {
         if constexpr ((ABL & 128) != 0) {
             const int ts = t - t_begin - 8;
@@ -420,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     const bool dma_last = !dma_first && !dma_mid;
     const bool emit_early = (a.mode & 4) == 0 || (rb & 1) == 0;
     for (int t = t_begin; t < t_end; ++t) {
-        asm volatile("" : "+s"(n[0]), "+s"(n[1]), "+s"(nd[0]), "+s"(nd[1]), "+s"(nl[0]), "+s"(nl[1]));
+        asm volatile("" : "+s"(n[0]), "+s"(n[1]), "+s"(nd[0]), "+s"(nd[1]), "+s"(nl[0]), "+s"(nl[1]), "+s"(kk[0]), "+s"(kk[1]));
         // ---- phase A: region A holds step t once every wave's pieces have landed; the slab holds
         // the dense sums of step t - 1 (written before this barrier, next written after the next one)
         stamp(t, 0);
@@ -428,9 +493,18 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
         stamp(t, 1);
         if (dma_first) dma_segment(x_step, h_step, piecesB);
         stamp(t, 2);
-        SGP_PHASE(0, if (emit_early && t > t_begin) emit(y_step - y_inc);,
-                     if (!emit_early && t > t_begin) emit(y_step - y_inc);
-                     if (dma_mid) dma_segment(x_step, h_step, piecesB);)
+        if constexpr (ILV) {
+            // (the older half's refill pieces after iteration 2 of the loop or, if it is shorter, after it)
+            bool dma_due = dma_mid;
+            SGP_PHASE_ILV(0, if (emit_early && t > t_begin) emit(y_step - y_inc);,
+                             if (dma_due) { dma_segment(x_step, h_step, piecesB); dma_due = false; },
+                             if (!emit_early && t > t_begin) emit(y_step - y_inc);
+                             if (dma_due) dma_segment(x_step, h_step, piecesB);)
+        } else {
+            SGP_PHASE(0, if (emit_early && t > t_begin) emit(y_step - y_inc);,
+                         if (!emit_early && t > t_begin) emit(y_step - y_inc);
+                         if (dma_mid) dma_segment(x_step, h_step, piecesB);)
+        }
         stamp(t, 3);
         if (dma_last) dma_segment(x_step, h_step, piecesB);
         // ---- phase B
@@ -440,7 +514,13 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
         stamp(t, 5);
         if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         stamp(t, 6);
-        SGP_PHASE(1, , if (dma_mid && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);)
+        if constexpr (ILV) {
+            bool dma_due = dma_mid && t + 1 < t_end;
+            SGP_PHASE_ILV(1, , if (dma_due) { dma_segment(x_step + x_inc, h_step + h_inc, piecesA); dma_due = false; },
+                             if (dma_due) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);)
+        } else {
+            SGP_PHASE(1, , if (dma_mid && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);)
+        }
         stamp(t, 7);
         if (dma_last && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -450,6 +530,14 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     emit(y_step - y_inc);
 #undef SGP_PHASE
+#undef SGP_PHASE_ILV
+#undef SGP_DENSE_MFMA
+#undef W_IDENSE
+#undef W_ISPARSE
+#undef I_POSN
+#undef I_POSS
+#undef I_A
+#undef I_B
 #undef SGP_SLOT
 #undef SGP_SLOT4
 #undef SGP_MF
@@ -472,7 +560,7 @@ unsigned* mix_dbg_buffer() {
 
 int g_mix_mode = -1;
 int mix_mode() {
-    if (g_mix_mode < 0) { const char* e = getenv("SGP_MIX_MODE"); g_mix_mode = e ? atoi(e) : 0; }
+    if (g_mix_mode < 0) { const char* e = getenv("SGP_MIX_MODE"); g_mix_mode = e ? atoi(e) : 6; }
     return g_mix_mode;
 }
 int mix_chunk_cap() {
@@ -483,11 +571,11 @@ int mix_chunk_cap() {
 
 #ifndef SGP_MIX_SH
 #define SGP_MIX_SH 12
-#define SGP_MIX_DH 8
+#define SGP_MIX_DH 10
 #define SGP_MIX_SHH 8
 #define SGP_MIX_DHH 7
-#define SGP_MIX_D 3
-#define SGP_MIX_DD 3
+#define SGP_MIX_D 2
+#define SGP_MIX_DD 2
 #endif
 #ifndef SGP_MIX_DDH
 #define SGP_MIX_DDH 3
@@ -495,7 +583,7 @@ int mix_chunk_cap() {
 constexpr int kSH = SGP_MIX_SH, kDH = SGP_MIX_DH;             // resident sparse super-steps / dense instructions per phase
 constexpr int kSHh = SGP_MIX_SHH, kDHh = SGP_MIX_DHH;           // with a halo source
 
-template <bool HALO, int SH, int DH, int D, int DD>
+template <bool HALO, int SH, int DH, int D, int DD, bool ILV>
 int launch_mix(const MixArgs& a, hipStream_t s) {
     const size_t lds_bytes = 160 * 1024;
     dim3 grid((unsigned)(a.n_tiles * a.n_tchunks), a.feat / 64);
@@ -504,7 +592,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
     if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
 #define SGP_ABL(V)                                                                                 \
     if (abl == V) {                                                                                \
-        auto k4 = spmm_mix<HALO, SH, DH, D, DD, V>;                                                \
+        auto k4 = spmm_mix<HALO, SH, DH, D, DD, ILV, V>;                                                \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_mix");                                                      \
@@ -512,7 +600,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
     SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129)
 #undef SGP_ABL
 #endif
-    auto kern = spmm_mix<HALO, SH, DH, D, DD>;
+    auto kern = spmm_mix<HALO, SH, DH, D, DD, ILV>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "spmm_mix: LDS opt-in: %s", hipGetErrorString(e));
@@ -581,7 +669,14 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
 #ifdef SGP_ABLATION
     a.dbg = mix_dbg_buffer();
 #endif
-    return Xh ? launch_mix<true, kSHh, kDHh, SGP_MIX_D, SGP_MIX_DDH>(a, s) : launch_mix<false, kSH, kDH, SGP_MIX_D, SGP_MIX_DD>(a, s);
+    if (Xh) return launch_mix<true, kSHh, kDHh, SGP_MIX_D, SGP_MIX_DDH, false>(a, s);
+    // (the interleaved form of a phase -- mode bit 5 -- measured slower than the plain one: 10.7 vs 10.1 ms
+    // per 512 steps without staging; kept for the record, built only where its static counts hold)
+    constexpr bool kIlvOk = kDH + SGP_MIX_D <= kSH && kDH <= kSH - 2 * SGP_MIX_D + 1 + SGP_MIX_DD;
+    if constexpr (kIlvOk) {
+        if (mix_mode() & 32) return launch_mix<false, kSH, kDH, SGP_MIX_D, SGP_MIX_DD, true>(a, s);
+    }
+    return launch_mix<false, kSH, kDH, SGP_MIX_D, SGP_MIX_DD, false>(a, s);
 }
 
 }  // extern "C"

@@ -73,7 +73,7 @@ def test_spmm_csr_strided_slots_in_place():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     buf = torch.randn(t, n, p * d, device="cuda")
     ref = buf.clone()
-    for force in ("csr", "tiled", "mfma", "pipe", "res"):
+    for force in ("csr", "tiled", "mfma", "pipe", "res", "mix"):
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
@@ -91,7 +91,7 @@ def test_spmm_tiled_knn(n, k, feat):
     plan = op.tile_plan(feat, torch.device("cuda"))
     assert plan is not None
     x = torch.randn(5, n, feat)
-    for force in ("tiled", "mfma", "pipe", "res"):
+    for force in ("tiled", "mfma", "pipe", "res", "mix"):
         y = torch.full((5, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -152,7 +152,7 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     op = graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n)
     assert op.tile_plan(feat, torch.device("cuda")) is not None
     x = torch.randn(t, n, feat)
-    for force in ("tiled", "mfma", "pipe", "res"):
+    for force in ("tiled", "mfma", "pipe", "res", "mix"):
         y = torch.full((t, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -794,7 +794,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("blk", "res", "pipe", "mfma", "tiled", "csr"):
+    for force in ("mix", "blk", "res", "pipe", "mfma", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity
@@ -822,9 +822,11 @@ def test_properties_on_the_target_graph():
     assert plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc, yr = (torch.empty_like(x1) for _ in range(4))
-    op.propagate(x1, ya); assert op.last_kernel == "spmm_res"
+    op.propagate(x1, ya); assert op.last_kernel == "spmm_mix"       # the default on this graph (round 3)
     op.propagate(x1, yr, force="blk")
     close(ya, yr, rtol=1e-6, atol=1e-6)
+    op.propagate(x1, yc, force="res"); assert op.last_kernel == "spmm_res"
+    close(yc, yr, rtol=1e-6, atol=1e-6)
     op.propagate(x2, yb)
     op.propagate(2 * x1 - 3 * x2, yc)
     close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)
@@ -859,7 +861,7 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
         assert blk.n_halo > 0
         xo = x[:, blk.lo:blk.hi].cuda().contiguous()
         recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()      # [rows, T, D]
-        for force in ("csr", "tiled", "mfma", "pipe", "res", "blk"):
+        for force in ("csr", "tiled", "mfma", "pipe", "res", "blk", "mix"):
             y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
             blk.op.propagate(xo, y, force=force, halo=recv.permute(1, 0, 2))
             close(y, ref[:, blk.lo:blk.hi])

@@ -9,7 +9,7 @@ import torch
 from sgp_amd import graph, mixplan, partition, synthetic
 
 LIMITS = dict(max_union=448, max_tile_rows=64, max_row_edges=128)
-DH = 9
+DH = 10
 
 
 def _plan(op, thr=4, dh=DH, order=None):
@@ -56,7 +56,7 @@ def test_plan_reproduces_the_operator(n, k, thr):
 def test_dense_cap_demotes_to_the_sparse_stream():
     ei, ew, _ = synthetic.knn_graph(1300, 100, seed=3)
     op = graph.ShiftOperator.from_edges(ei, ew, 1300)
-    wide, narrow = _plan(op, dh=9), _plan(op, dh=3)
+    wide, narrow = _plan(op, dh=10), _plan(op, dh=3)
     assert narrow.max_dense == 3 and narrow.dense_share < wide.dense_share
     _check(op, narrow)
 

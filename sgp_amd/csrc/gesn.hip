@@ -287,7 +287,10 @@ int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
     // sequence to the stepwise path below, which restarts from h_state
     int t_done = 0;
     bool used_persistent = false;
+    constexpr int kBarSticky = 400;           // (gesn_persist.hip) failure word outside the per-launch memset
     if (sgp_gesn::mode()) {
+        e = hipMemsetAsync(reinterpret_cast<unsigned*>(base + ws.bar) + kBarSticky, 0, sizeof(unsigned), stream);
+        if (e != hipSuccess) return sgp::fail((int)e, "sgp_gesn_f32: %s", hipGetErrorString(e));
         for (; t_done < T && !rc; t_done += kStepChunk) {
             const int tc = T - t_done < kStepChunk ? T - t_done : kStepChunk;
             rc = input_term(t_done, tc);
@@ -308,7 +311,7 @@ int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
         if (rc) return rc;
         if (used_persistent) {
             unsigned failed = 0;
-            e = hipMemcpyAsync(&failed, reinterpret_cast<unsigned*>(base + ws.bar) + 1, sizeof(unsigned),
+            e = hipMemcpyAsync(&failed, reinterpret_cast<unsigned*>(base + ws.bar) + kBarSticky, sizeof(unsigned),
                                hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return sgp::fail((int)e, "sgp_gesn_f32: %s", hipGetErrorString(e));

@@ -81,6 +81,7 @@ __device__ __forceinline__ void st4_agent(float* p, f32x4 v) {
 // workgroups serialises their read-modify-writes at the coherence point (6.5 us per tick measured);
 // per-workgroup flags polled by one wave (4 coalesced loads per poll) came out the same as this (16.6 vs 16.0 us per tick).
 constexpr int kBarGroups = 16;
+constexpr int kBarSticky = 400;                    // failure flag of the whole call (gesn.hip clears it once per call)
 constexpr int kBarWords = 16 + 16 * kBarGroups;   // [0] top, [1] failure flag, [16 + 16 g] group g
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned round, int* lds_flag) {
     // my stores have been acknowledged by the coherence point before anyone can see my arrival
@@ -105,7 +106,12 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned round, int*
                 break;
             }
         }
-        if (!ok) __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!ok) {
+            __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // sticky copy outside the words that every launch clears: a time-out in an early chunk of a
+            // call must still be visible when the host looks after the last one
+            __hip_atomic_store(&bar[kBarSticky], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         *lds_flag = ok;
     }
     __syncthreads();

@@ -31,6 +31,29 @@ def _rect_dense(a, x3, dst):
     ShiftOperator(rowptr, c, a[r, c], a.shape[0], num_cols=a.shape[1]).propagate_rect(x3, dst)
 
 
+_CONSTANT_CACHE = {}
+
+
+def _constant_value(adj):
+    """The single value of a dense support whose entries are all equal (the reference's global_attr
+    support: 1 / N everywhere), else None.  Looked at once per support object: the N x N matrix is not
+    copied to the host and compared on every batch."""
+    key = id(adj)
+    hit = _CONSTANT_CACHE.get(key)
+    if hit is not None and hit[0] is adj:
+        return hit[1]
+    a = torch.as_tensor(adj)
+    value = None
+    if a.numel():
+        c = a.flatten()[0]
+        if bool((a == c).all()):
+            value = float(c)
+    if len(_CONSTANT_CACHE) > 64:
+        _CONSTANT_CACHE.clear()
+    _CONSTANT_CACHE[key] = (adj, value)
+    return value
+
+
 def apply_supports(x, support, node_index=None):
     """x[..., N, F] -> [..., N (or len(node_index)), (1 + len(support)) * F]."""
     hip.require_gpu()
@@ -60,12 +83,11 @@ def apply_supports(x, support, node_index=None):
             # sgp_preprocessing.py:157-158): a constant matrix times x is the scaled column sum of
             # x in every row -- sgp_node_sums / sgp_bcast_rows, no N x N product.  Any other dense
             # matrix goes through the CSR kernel like the sparse supports.
-            a = torch.as_tensor(adj, dtype=torch.float32).cpu()
-            a = a if idx is None else a[idx]
-            c = float(a.flatten()[0]) if a.numel() else 0.0
-            if a.numel() and bool((a == c).all()):
-                hip.bcast_rows(hip.node_sums(x3), c, dst)
+            const = _constant_value(adj)          # decided once per support object, not per batch
+            if const is not None:
+                hip.bcast_rows(hip.node_sums(x3), const, dst)
             else:
-                _rect_dense(a, x3, dst)
+                a = torch.as_tensor(adj, dtype=torch.float32).cpu()
+                _rect_dense(a if idx is None else a[idx.cpu()], x3, dst)
     out = out.reshape(*lead, rows, out.shape[-1])
     return out if dev_in == out.device else out.to(dev_in)

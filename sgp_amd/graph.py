@@ -266,7 +266,14 @@ class ShiftOperator:
         if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
             raise ValueError("halo batch / feature size differs from x")
         plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
-        halo_fits = not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30)
+        # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,
+        # far * xhrs, n_rows * yrs < 2^30); beyond that -- e.g. a [rows, T, D] halo receive buffer of a
+        # long time chunk, whose row stride is T * D -- the generic CSR kernel (64-bit addressing) serves
+        fits32 = x.shape[1] * max(x.stride(1), 1) < 2 ** 30 and y.shape[1] * max(y.stride(1), 1) < 2 ** 30 and \
+            not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30)
+        if not fits32 and force in (None, "csr"):
+            plan = None
+        halo_fits = fits32
         # mixed dense (16x16x4) / sparse (4x4x1) kernel: first choice where the planner finds enough shared
         # columns (k-NN-like graphs; measured 1-2 % faster than spmm_res on the 100-NN target graph);
         # SGP_SPMM_DEFAULT=res switches it off

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from ... import hip
+from .init import draw_reservoir_weights
 
 _ACTIVATIONS = ['tanh', 'relu', 'self_norm', 'identity']
 
@@ -55,21 +56,16 @@ class ReservoirLayer(nn.Module):
         self.reset_parameters()
 
     def reset_parameters(self):
-        """RNG order of reservoir.py:54-75: w_ih, b_ih, w_hh, randperm mask, eigvals."""
-        self.w_ih.data.uniform_(-1, 1)
-        self.w_ih.data.mul_(self.w_ih_scale)
-        if self.b_ih is not None:
-            self.b_ih.data.uniform_(-1, 1)
-            self.b_ih.data.mul_(self.b_scale)
-        self.w_hh.data.uniform_(-1, 1)
-        if self.density < 1:
-            n_units = self.hidden_size * self.hidden_size
-            mask = self.w_hh.data.new_ones(n_units)
-            masked_weights = torch.randperm(n_units)[:int(n_units * (1 - self.density))]
-            mask[masked_weights] = 0.
-            self.w_hh.data.mul_(mask.view(self.hidden_size, self.hidden_size))
-        abs_eigs = torch.linalg.eigvals(self.w_hh.data.cpu()).abs()
-        self.w_hh.data.mul_((self.spectral_radius / torch.max(abs_eigs)).to(self.w_hh.device))
+        """Re-draw the layer from the global torch RNG (``init.draw_reservoir_weights`` keeps the
+        reference's draw order, so a seed reproduces the reference's parameters)."""
+        w_in, bias, w_rec = draw_reservoir_weights(
+            self.input_size, self.hidden_size, density=self.density,
+            spectral_radius=self.spectral_radius, in_scaling=self.w_ih_scale,
+            bias_scale=self.b_scale, with_bias=self.b_ih is not None)
+        self.w_ih.data.copy_(w_in)
+        self.w_hh.data.copy_(w_rec)
+        if bias is not None:
+            self.b_ih.data.copy_(bias)
 
     def _device_weights(self, device):
         b = self.b_ih if self.b_ih is not None else torch.zeros(self.hidden_size)

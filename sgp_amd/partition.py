@@ -197,6 +197,7 @@ class PartitionedSpatial:
         self._dist = self.world_size > 1 or (force_collectives and dist.is_initialized())
         self._xchg = {}
         self._comm_stream = None
+        self._res_stream = None                    # encode_partitioned: reservoir of the next time piece
         # bench.py sets this to a list: (kind, start event, end event) per exchange ("comm", on the
         # communication stream) and per SpMM launch ("hop", on the compute stream)
         self.timeline = None
@@ -298,6 +299,43 @@ class PartitionedSpatial:
         return out
 
 
+def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=None, pieces=None):
+    """Reservoir + K hops (+ global block) of the local node block with the reservoir of time
+    piece c + 1 running UNDER the hops and halo exchange of piece c ("reservoir chunk
+    c + 1 || SpMM chunk c || halo chunk c").  The recurrence is sequential in time, so the pieces of
+    the reservoir follow each other on their own stream with the state carried in ``state``
+    [L, n_own, R]; the propagation is independent per time step, so piece c's hops only wait for
+    piece c's states.  Same kernels on the same data as reservoir-then-hops: identical results.
+    ``x[T, n_own, F]``, ``out[T, n_own, P * D_h]`` on the GPU."""
+    T = x.shape[0]
+    d_h = reservoir.output_size
+    pieces = spatial.n_chunks if pieces is None else pieces
+    pieces = max(1, min(int(pieces), T // 8)) if x.is_cuda else 1
+    if pieces <= 1 or not x.is_cuda:
+        reservoir.encode_into(x, out[:, :, :d_h], state)
+        return spatial.encode_into(out, d_h)
+    if state is None:
+        state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
+                            dtype=torch.float32, device=x.device)
+    main = torch.cuda.current_stream(x.device)
+    if spatial._res_stream is None:
+        spatial._res_stream = torch.cuda.Stream(device=x.device)
+    side = spatial._res_stream
+    side.wait_stream(main)                                  # (x / out / state of the caller)
+    cuts = [(T * j) // pieces for j in range(pieces + 1)]
+    for j in range(pieces):
+        t0, t1 = cuts[j], cuts[j + 1]
+        with torch.cuda.stream(side):
+            reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state)
+            ready = torch.cuda.Event()
+            ready.record(side)
+        main.wait_event(ready)
+        spatial.encode_into(out[t0:t1], d_h)
+    for t in (x, out, state):
+        t.record_stream(side)
+    return out
+
+
 def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
                              rank=None, world_size=None, group=None, ops=HipOps,
                              balance="nnz", n_chunks=4, force_collectives=False, locality="auto"):
@@ -333,6 +371,11 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
             cb = cut(cand)
             if locality == "always" or 10 * halo_rows(cand[0], cb, mid) < 7 * plain:
                 ops_global, bounds, node_order = cand, cb, order
+                if locality == "auto":
+                    import warnings
+                    warnings.warn("make_partitioned_spatial: the node numbering has no locality; rank r owns "
+                                  "spatial.node_order[bounds[r]:bounds[r+1]], not the contiguous range "
+                                  "(pass locality='never' to keep the numbering)", stacklevel=2)
     blocks = [split_operator(op, bounds, rank) for op in ops_global]
     spatial = PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
                                  n_chunks=n_chunks, force_collectives=force_collectives)

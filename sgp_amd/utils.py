@@ -27,39 +27,52 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     constructor arguments, per-layer leaking rates and weights are written next to the tensor
     (``save_path + '.encoder.pt'``) so that the embedding can be re-derived (lib/utils.py:34-35
     saves the tensor only, the random weights are lost)."""
-    if isinstance(encode_exogenous, bool):
-        preprocess_exogenous = dataset.exogenous.keys() if encode_exogenous else []
-    else:
-        preprocess_exogenous = encode_exogenous
-    preprocess_exogenous = ensure_list(preprocess_exogenous)
-
-    x, _ = dataset.get_tensors(['data'] + preprocess_exogenous, preprocess=True, cat_dim=-1)
-
+    exo_keys = _exogenous_to_encode(dataset, encode_exogenous)
+    x, _ = dataset.get_tensors(['data'] + exo_keys, preprocess=True, cat_dim=-1)
     encoder = encoder_class(**encoder_kwargs)
 
-    start = time()
+    started = time()
     if return_device:                 # every encoder answers on the device of its input
         from . import hip
         hip.require_gpu()
         x = x.cuda()
-    encoded_x = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight)
-    elapsed = int(time() - start)
+    embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight)
+    seconds = int(time() - started)
+    logger.info(f"Dataset encoded in {seconds // 60}:{seconds % 60:02d} minutes.")
 
     if save_path is not None:
-        torch.save(encoded_x, save_path)
+        torch.save(embedding, save_path)
         if hasattr(encoder, "describe"):
             torch.save(encoder.describe(), str(save_path) + ".encoder.pt")
 
-    logger.info(f"Dataset encoded in {elapsed // 60}:{elapsed % 60:02d} minutes.")
-
-    dataset.add_exogenous('encoded_x', encoded_x, add_to_input_map=False)
-
-    input_map = {'x': ['encoded_x']}
-    u = ([] if encode_exogenous else ['u']) + (['data'] if keep_raw else [])
-    if len(u):
-        input_map['u'] = u
-    dataset.set_input_map(input_map)
+    # the embedding becomes the model input 'x'; what was not encoded stays available as 'u'
+    dataset.add_exogenous('encoded_x', embedding, add_to_input_map=False)
+    dataset.set_input_map(_input_map_after_encoding(encode_exogenous, keep_raw))
     return dataset
+
+
+def _exogenous_to_encode(dataset, encode_exogenous):
+    """True -> every exogenous variable of the dataset, False -> none, a name or list of names ->
+    those (lib/utils.py:19-23; the reference only handles the two booleans)."""
+    if encode_exogenous is True:
+        return list(dataset.exogenous.keys())
+    if encode_exogenous is False:
+        return []
+    return ensure_list(encode_exogenous)
+
+
+def _input_map_after_encoding(encode_exogenous, keep_raw):
+    """lib/utils.py:41-46: 'x' is the embedding; 'u' keeps the un-encoded exogenous 'u' (only when
+    nothing exogenous was encoded) and, on request, the raw series."""
+    side = []
+    if not encode_exogenous:
+        side.append('u')
+    if keep_raw:
+        side.append('data')
+    mapping = {'x': ['encoded_x']}
+    if side:
+        mapping['u'] = side
+    return mapping
 
 
 def self_normalizing_activation(x: Tensor, r: float = 1.0):

@@ -898,6 +898,69 @@ def test_bench_two_ranks_share_one_gpu_matches_single_rank(tmp_path):
     close(torch.cat(parts, 1), full, rtol=1e-6, atol=1e-6)
 
 
+def _run_bench(args, env, timeout=1500):
+    import subprocess, sys, json
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env,
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_forced_collectives_take_the_rccl_branch_on_one_rank(tmp_path):
+    """SGP_BENCH_FORCE_DIST=1 with the default backend (nccl = RCCL): ONE rank runs the whole
+    partitioned path -- RCCL init, the device ``all_to_all_single`` of ``HaloExchange``, the device
+    ``all_reduce`` of the global block, the (hop, time chunk) pipeline on the communication stream and
+    the reservoir of the next time piece on its own stream -- and must reproduce the plain
+    single-rank result (same kernels, same plan; the global block goes through node_sums + scale
+    instead of the fused mean: 1e-6)."""
+    env = dict(os.environ, SGP_BENCH_DUMP=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "SGP_BENCH_BACKEND"):
+        env.pop(k, None)
+    base = ["--workload", "small", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    _run_bench(base, env)
+    plain = torch.load(tmp_path / "out_w1_r0.pt")
+    os.rename(tmp_path / "out_w1_r0.pt", tmp_path / "plain.pt")
+    rec = _run_bench(base, dict(env, SGP_BENCH_FORCE_DIST="1", MASTER_PORT=str(29900 + os.getpid() % 90)))
+    assert rec["config"]["backend"] == "nccl" and rec["n_gpus"] == 1
+    assert "multi_gpu" in rec and rec["multi_gpu"]["time_chunks_per_hop"] > 1      # the pipelined branch ran
+    forced = torch.load(tmp_path / "out_w1_r0.pt")
+    d_h = 64
+    assert torch.equal(forced[:, :, :-d_h], plain[:, :, :-d_h])                   # reservoir + every hop block
+    close(forced[:, :, -d_h:], plain[:, :, -d_h:], rtol=1e-6, atol=1e-6)           # global block
+
+
+@pytest.mark.parametrize("workload,gpus,t_steps,stride", [("c4", 2, 96, 1), ("c4", 4, 96, 1), ("c5", 8, 8, 61)])
+def test_bench_baseline_partitioned_configs_share_one_gpu(tmp_path, workload, gpus, t_steps, stride):
+    """BASELINE.json's partitioned configurations in the form it names them -- C4 (PV-US shape:
+    N = 5016, 100-NN, 16 units x 8 layers, K = 2, global block) on 2 and 4 ranks, C5 (N = 100 000,
+    F = 128, 256 units, K = 5) on 8 ranks -- at reduced T, the ranks sharing this box's GPU over
+    gloo: the concatenated result equals the single-rank run (C5: every 61st node)."""
+    env = dict(os.environ, SGP_BENCH_DUMP=str(tmp_path), SGP_BENCH_DUMP_STRIDE=str(stride))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = ["--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--t-steps", str(t_steps)]
+    _run_bench(base, env)
+    rec = _run_bench(base + ["--gpus", str(gpus)], env, timeout=2400)
+    assert rec["n_gpus"] == gpus and rec["config"]["backend"] == "gloo" and rec["multi_gpu"]["halo_rows_in"] > 0
+    if stride == 1:
+        full = torch.load(tmp_path / "out_w1_r0.pt")
+        parts = torch.cat([torch.load(tmp_path / f"out_w{gpus}_r{r}.pt") for r in range(gpus)], 1)
+        close(parts, full, rtol=1e-5, atol=1e-5)
+    else:
+        one = torch.load(tmp_path / "out_w1_r0.pt")
+        ref = {int(i): k for k, i in enumerate(one["ids"])}
+        seen = 0
+        for r in range(gpus):
+            part = torch.load(tmp_path / f"out_w{gpus}_r{r}.pt")
+            idx = torch.tensor([ref[int(i)] for i in part["ids"]], dtype=torch.long)
+            close(part["out"], one["out"][:, idx], rtol=1e-5, atol=1e-5)
+            seen += idx.numel()
+        assert seen == one["ids"].numel()
+
+
 def test_bench_under_an_external_launcher(tmp_path):
     """The launcher form of the contract (torch.distributed.run starts the ranks) still works."""
     import subprocess, sys, json

@@ -299,6 +299,19 @@ int sgp_reservoir_fused_f32(const float* x, int64_t x_row_stride, int64_t x_step
                             float* h_state, void* workspace,
                             int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
                             sgp_stream_t stream);
+/* Same, and the column sums of the produced states per node tile of 16:
+ *   tile_sums[ceil(N / 16)][T][L*R] (contiguous, 16-byte aligned), entry (k, t, :) = sum over the
+ *   nodes 16 k .. 16 k + 15 (< N) of out[t, node, :L*R].
+ * The global_attr block of lib/nn/encoders/sgp_spatial_encoder.py:32-34 is the mean over nodes of
+ * exactly this tensor: summing the tiles (sgp_node_mean_bcast_f32 with Y = NULL over the [T, tiles, D]
+ * view) replaces a second pass over the whole block.  NULL = sgp_reservoir_fused_f32. */
+int sgp_reservoir_fused_sums_f32(const float* x, int64_t x_row_stride, int64_t x_step_stride,
+                                 const float* const* w_ih, const float* const* w_hh, const float* const* b,
+                                 const double* alpha, int32_t act,
+                                 float* out, int64_t out_row_stride, int64_t out_step_stride,
+                                 float* h_state, void* workspace, float* tile_sums,
+                                 int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
+                                 sgp_stream_t stream);
 
 /* --------------------------------------------------------------- DynGESN ---
  * The graph echo-state baseline (lib/nn/reservoir/graph_reservoir.py:85-93, stepped by

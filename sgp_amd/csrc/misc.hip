@@ -72,6 +72,24 @@ __global__ __launch_bounds__(256) void bcast_rows_kernel(
     }
 }
 
+// feat % 4 == 0 and feat <= 1024: a thread keeps its 16 bytes of the (scaled) source row in registers and
+// writes them to every row of its workgroup's row range (streamed stores: the block is written once
+// and read by nobody on this GPU before it leaves) -- no index arithmetic or source load per element
+__global__ __launch_bounds__(256) void bcast_rows_wide_kernel(
+        const float* __restrict__ src, float scale, float* __restrict__ Y, long long yrs, long long ybs,
+        int n_rows, int feat, int rows_per_wg) {
+    const int b = blockIdx.y;
+    const int per_row = feat >> 2;                       // float4 pieces per row (<= 256)
+    const int rows_in_flight = 256 / per_row;
+    const int piece = threadIdx.x % per_row, rsub = threadIdx.x / per_row;
+    if (rsub >= rows_in_flight) return;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long long)b * feat + piece * 4) * scale;
+    const int r_end = min(n_rows, (int)(blockIdx.x + 1) * rows_per_wg);
+    float* yp = Y + (long long)b * ybs + piece * 4;
+    for (int r = blockIdx.x * rows_per_wg + rsub; r < r_end; r += rows_in_flight)
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(yp + (long long)r * yrs));
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void copy_rows_kernel(
         const float* __restrict__ X, long long xrs, long long xbs,
@@ -132,7 +150,15 @@ int sgp_bcast_rows_f32(const float* src, float scale, float* Y, int64_t yrs, int
     SGP_REQUIRE(n_rows >= 0 && batch >= 0 && feat >= 0 && batch <= 65535, "sgp_bcast_rows_f32: bad size");
     if (!n_rows || !batch || !feat) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (vec_ok(Y, yrs, ybs, feat) && sgp::aligned16(src))
+    if (vec_ok(Y, yrs, ybs, feat) && sgp::aligned16(src) && feat <= 1024) {
+        // enough workgroups to fill the chip, each with a few hundred rows to stream
+        long long want = 8192 / (batch < 1 ? 1 : batch);
+        if (want < 1) want = 1;
+        int rows_per_wg = (int)((n_rows + want - 1) / want);
+        if (rows_per_wg < 64) rows_per_wg = 64;
+        hipLaunchKernelGGL(bcast_rows_wide_kernel, dim3((n_rows + rows_per_wg - 1) / rows_per_wg, batch), dim3(256),
+                           0, s, src, scale, Y, yrs, ybs, n_rows, feat, rows_per_wg);
+    } else if (vec_ok(Y, yrs, ybs, feat) && sgp::aligned16(src))
         hipLaunchKernelGGL(bcast_rows_kernel<4>, dim3(grid_for((long long)n_rows * feat / 4), batch), dim3(256),
                            0, s, src, scale, Y, yrs, ybs, n_rows, feat);
     else

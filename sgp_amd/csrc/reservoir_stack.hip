@@ -35,6 +35,7 @@ struct StackArgs {
     const float* wp;                 // packed weights of all layers (global workspace)
     float* out; long long ors, oss;
     float* h_state;                  // [L, N, R] or null
+    float* tsum;                     // [n_tiles, T, L*R] per-tile column sums of the states, or null
     float alpha[kMaxLayers], oma[kMaxLayers];
     int act, T, N, F, R, L, ntw, n_tiles, debug;
 };
@@ -103,7 +104,37 @@ __global__ void pack_stack(StackPtrs ptr, float* __restrict__ out, int F, int R,
 
 // OVEC: 16-byte state stores (strides / pointers checked on the host) -- a compile-time switch: with
 // both store flavours in the loop body hipcc's s_waitcnt bookkeeping drains vmcnt(0) every step.
-template <int JT, int NKX, bool OVEC>
+// sums over the 16 lanes of a DPP row (= the 16 nodes of a tile that share q) of four values at once:
+// quad butterfly, then the two mirrors; every lane ends up with its row's totals.  v_add_f32_dpp from
+// inline asm (hipcc emits v_mov_b32_dpp + v_add_f32: twice the VALU instructions, and VALU time is
+// matrix-pipe time in this kernel); a DPP source written by the previous VALU instruction needs two
+// wait states: the four independent chains are interleaved, three instructions lie in between.
+__device__ __forceinline__ void row16_sum4(f32x4& v) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf"
+        : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
+}
+
+// CSUM: also write the column sums of every tile's states (global_attr block of
+// lib/nn/encoders/sgp_spatial_encoder.py:32-34: the mean over nodes of the tensor the reservoir just
+// produced) -- the rows are in registers here; a separate pass re-reads the whole block from HBM.
+template <int JT, int NKX, bool OVEC, bool CSUM>
 __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
     constexpr int WIN = win_floats(JT, NKX);
     constexpr int LB = layer_floats(JT, NKX);
@@ -150,6 +181,7 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
         h[jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
     }
     float* const out_l = a.out + (long long)node * a.ors + (long long)l * a.R;
+    const bool tail_tile = tile * 16 + 16 > a.N;         // wave-uniform
     bool st_ok[JT];
 #pragma unroll
     for (int jt = 0; jt < JT; ++jt) st_ok[jt] = ok && 16 * jt + 4 * q < a.R && !(a.debug & 1);
@@ -165,6 +197,21 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         if (j0 + r < a.R) op[r] = h[jt][r];
+                }
+            }
+            if constexpr (CSUM) {
+                f32x4 v = h[jt];
+                if (tail_tile && !ok) v = f32x4{0.f, 0.f, 0.f, 0.f};      // rows past N (last tile) do not count
+                row16_sum4(v);
+                if (n_in == 0 && tile < a.n_tiles && j0 < a.R) {
+                    float* sp = a.tsum + ((long long)tile * a.T + t) * ((long long)a.L * a.R) + (long long)l * a.R + j0;
+                    if constexpr (OVEC) {
+                        *reinterpret_cast<f32x4*>(sp) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (j0 + r < a.R) sp[r] = v[r];
+                    }
                 }
             }
         }
@@ -378,8 +425,10 @@ int launch_stack(StackArgs a, hipStream_t s) {
     if (stack_lds_bytes<JT, NKX>(a.L, ntw) > kLdsLimit)
         return sgp::fail(SGP_EUNSUP, "sgp_reservoir_fused_f32: %d layers of %d units exceed the LDS", a.L, a.R);
     a.ntw = ntw;
-    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
-    auto kern = ov ? reservoir_stack<JT, NKX, true> : reservoir_stack<JT, NKX, false>;
+    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out) &&
+                    (!a.tsum || sgp::aligned16(a.tsum));
+    auto kern = a.tsum ? (ov ? reservoir_stack<JT, NKX, true, true> : reservoir_stack<JT, NKX, false, true>)
+                       : (ov ? reservoir_stack<JT, NKX, true, false> : reservoir_stack<JT, NKX, false, false>);
     const int bytes = (int)stack_lds_bytes<JT, NKX>(a.L, ntw);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
@@ -432,6 +481,17 @@ int sgp_reservoir_fused_f32(const float* x, int64_t xrs, int64_t xss,
                             float* h_state, void* workspace,
                             int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
                             sgp_stream_t stream) {
+    return sgp_reservoir_fused_sums_f32(x, xrs, xss, w_ih, w_hh, b, alpha, act, out, ors, oss, h_state,
+                                        workspace, nullptr, T, N, F, R, L, stream);
+}
+
+int sgp_reservoir_fused_sums_f32(const float* x, int64_t xrs, int64_t xss,
+                                 const float* const* w_ih, const float* const* w_hh, const float* const* b,
+                                 const double* alpha, int32_t act,
+                                 float* out, int64_t ors, int64_t oss,
+                                 float* h_state, void* workspace, float* tile_sums,
+                                 int32_t T, int32_t N, int32_t F, int32_t R, int32_t L,
+                                 sgp_stream_t stream) {
     SGP_REQUIRE(x && w_ih && w_hh && b && alpha && out && workspace, "sgp_reservoir_fused_f32: null pointer");
     SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0 && L >= 1, "sgp_reservoir_fused_f32: bad size");
     SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_reservoir_fused_f32: unknown activation %d", act);
@@ -458,6 +518,7 @@ int sgp_reservoir_fused_f32(const float* x, int64_t xrs, int64_t xss,
     a.wp = (const float*)workspace;
     a.out = out; a.ors = ors; a.oss = oss;
     a.h_state = h_state;
+    a.tsum = tile_sums;
     for (int l = 0; l < kMaxLayers; ++l) {
         const double al = l < L ? alpha[l] : 0.0;
         a.alpha[l] = (float)al;                    // scalars rounded to fp32 like torch does for

@@ -97,6 +97,12 @@ SIGNATURES = {
                                                c_p, c_i64, c_i64,
                                                c_p, c_p,
                                                c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_reservoir_fused_sums_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
+                                                    c_p, c_p, c_p,
+                                                    c_p, c_i32,
+                                                    c_p, c_i64, c_i64,
+                                                    c_p, c_p, c_p,
+                                                    c_i32, c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_gesn_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgp_gesn_tune": (ctypes.c_int, [c_i32]),
     "sgp_gesn_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
@@ -408,9 +414,12 @@ def reservoir_fused_supported(F, R, L):
 
 
 @_on_device
-def reservoir_stack(x, weights, alphas, activation, out, h_state=None):
+def reservoir_stack(x, weights, alphas, activation, out, h_state=None, col_sums=None):
     """All layers of a stacked reservoir in one launch: x[T, N, F] -> out[T, N, L*R] (views
-    allowed), ``weights`` = [(w_ih, w_hh, b)] per layer on the device, ``h_state`` [L, N, R]."""
+    allowed), ``weights`` = [(w_ih, w_hh, b)] per layer on the device, ``h_state`` [L, N, R].
+    ``col_sums`` [T, L*R] (contiguous): also receives the sum over nodes of every step's states (the
+    kernel writes per-tile sums from its registers, a small second launch adds the tiles) -- what
+    the global_attr block needs, without re-reading the states from HBM."""
     lib = require_gpu()
     xp, xrs, xss = _view3(x, "x")
     op, ors, oss = _view3(out, "out")
@@ -431,10 +440,18 @@ def reservoir_stack(x, weights, alphas, activation, out, h_state=None):
     ws = _workspace(x.device, wsb)
     ptrs = lambda k: (ctypes.c_void_p * L)(*[w[k].data_ptr() for w in weights])
     al = (ctypes.c_double * L)(*[float(a) for a in alphas])
-    _check(lib.sgp_reservoir_fused_f32(
+    tile_sums = None
+    if col_sums is not None:
+        if tuple(col_sums.shape) != (T, L * R) or not col_sums.is_contiguous() or col_sums.dtype != torch.float32:
+            raise ValueError("col_sums: expected contiguous float32 [T, L*R]")
+        tile_sums = torch.empty((N + 15) // 16, T, L * R, dtype=torch.float32, device=x.device)
+    _check(lib.sgp_reservoir_fused_sums_f32(
         xp, xrs, xss, ptrs(0), ptrs(1), ptrs(2), al, ACT_CODES[activation], op, ors, oss,
         h_state.data_ptr() if h_state is not None else None, ws.data_ptr(),
-        T, N, F, R, L, _stream(x)), "sgp_reservoir_fused_f32")
+        tile_sums.data_ptr() if tile_sums is not None else None,
+        T, N, F, R, L, _stream(x)), "sgp_reservoir_fused_sums_f32")
+    if tile_sums is not None and T > 0:
+        col_sums.copy_(node_sums(tile_sums.permute(1, 0, 2)))       # [T, tiles, D] view: rows = tiles
     return out
 
 

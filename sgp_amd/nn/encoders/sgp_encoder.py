@@ -153,9 +153,13 @@ class SGPEncoder(nn.Module):
         if out is None:
             out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
         chunks = self._overlap_pieces(T, N)
+        # global_attr: the column sums of the states come from the reservoir kernel where it has them
+        # in registers (fused stacked kernel); the other kernels keep the fused mean + broadcast pass
+        want_sums = self.sgp_encoder.global_attr and self.reservoir.produces_col_sums(x)
         if chunks <= 1:
-            self.reservoir.encode_into(x, out[:, :, :d_h], state)
-            self.sgp_encoder.encode_into(out, d_h, ops, timeline)
+            sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
+            self.reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
+            self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums)
             return out
         if state is None:
             state = torch.zeros(len(self.reservoir.reservoir_layers), N, self.reservoir.hidden_size,
@@ -168,12 +172,15 @@ class SGPEncoder(nn.Module):
         side.wait_stream(main)                                  # (out / earlier work of the caller)
         for j in range(chunks):
             t0, t1 = T * j // chunks, T * (j + 1) // chunks
-            self.reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state)
+            sums = torch.empty(t1 - t0, d_h, dtype=torch.float32, device=x.device) if want_sums else None
+            self.reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state, col_sums=sums)
             ready = torch.cuda.Event()
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline)
+                self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline, col_sums=sums)
+                if sums is not None:
+                    sums.record_stream(side)
         main.wait_stream(side)
         return out
 

@@ -33,14 +33,20 @@ class SGPSpatialEncoder(nn.Module):
                                  add_self_loops=self.add_self_loops,
                                  bidirectional=self.bidirectional)
 
-    def encode_into(self, out, feat, ops, timeline=None):
+    def encode_into(self, out, feat, ops, timeline=None, col_sums=None):
         """Device path.  ``out[B, N, P * feat]`` with slot 0 already filled: run the hops
         and the global-mean block in place (sgp_spatial_encoder.py:22-35 without the
-        ``torch.cat``)."""
+        ``torch.cat``).  ``col_sums`` [B, feat]: sums over the nodes of slot 0 when the producer
+        already has them (``Reservoir.encode_into``): the global block is then written without
+        reading slot 0 again."""
         propagate_into(out, feat, ops, self.receptive_field, timeline)
         if self.global_attr:          # :32-34
             p = self.num_blocks() - 1
-            hip.node_mean_bcast(out[:, :, :feat], out[:, :, p * feat:(p + 1) * feat])
+            slot = out[:, :, p * feat:(p + 1) * feat]
+            if col_sums is not None:
+                hip.bcast_rows(col_sums, 1.0 / out.shape[1], slot)
+            else:
+                hip.node_mean_bcast(out[:, :, :feat], slot)
         return out
 
     def forward(self, x, edge_index, edge_weight):

@@ -139,11 +139,13 @@ class Reservoir(nn.Module):
     def output_size(self):
         return len(self.reservoir_layers) * self.hidden_size
 
-    def encode_into(self, x, out, h_state=None):
+    def encode_into(self, x, out, h_state=None, col_sums=None):
         """Device path: x[T, M, F] (CUDA) -> out[T, M, L*R] view, layer-major features
         (reservoir.py:181-183).  Layer l > 0 consumes layer l-1's slot of ``out`` -- at
         step s its input is layer l-1's NEW state of step s, as in reservoir.py:174-176.
-        ``h_state``: optional [L, M, R] carried across time chunks."""
+        ``h_state``: optional [L, M, R] carried across time chunks.  ``col_sums`` [T, L*R]: filled
+        with the sums over the M rows of every step's states (the global_attr block is their mean);
+        the fused kernel produces them from its registers, the other kernels by a pass over ``out``."""
         R = self.hidden_size
         L = len(self.reservoir_layers)
         if self.fused and L > 1 and self._fusable(x):
@@ -151,16 +153,24 @@ class Reservoir(nn.Module):
             # layer inside one time step)
             weights = [layer._device_weights(x.device) for layer in self.reservoir_layers]
             hip.reservoir_stack(x, weights, [layer.alpha for layer in self.reservoir_layers],
-                                self.reservoir_layers[0].activation_name, out[:, :, :L * R], h_state)
+                                self.reservoir_layers[0].activation_name, out[:, :, :L * R], h_state,
+                                col_sums=col_sums)
             return out
         src = x
         for i, layer in enumerate(self.reservoir_layers):
             dst = out[:, :, i * R:(i + 1) * R]
             layer.run_sequence(src, dst, None if h_state is None else h_state[i])
             src = dst
+        if col_sums is not None:
+            col_sums.copy_(hip.node_sums(out[:, :, :L * R]))
         return out
 
     fused = True                    # set False to force one launch per layer
+
+    def produces_col_sums(self, x):
+        """True when ``encode_into(..., col_sums=)`` gets the sums from the kernel's registers (the
+        fused stacked kernel) rather than from a second pass over the states."""
+        return bool(self.fused and len(self.reservoir_layers) > 1 and x.is_cuda and self._fusable(x))
 
     def _fusable(self, x):
         """Narrow stacked reservoirs (R * L <= 256: the shipped sgp_pv.yaml has 16 x 8) whose

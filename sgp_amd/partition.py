@@ -280,14 +280,17 @@ class PartitionedSpatial:
         # the communication stream's buffers are reused by the next call: let it catch up
         comm.wait_stream(main)
 
-    def encode_into(self, out, feat):
+    def encode_into(self, out, feat, col_sums=None):
+        """``col_sums`` [T, feat]: sums over the OWNED rows of slot 0 when the producer has them
+        already (``Reservoir.encode_into``); they are all-reduced over the ranks like the sums this
+        method would otherwise compute from slot 0."""
         if self._dist and out.is_cuda and self.n_chunks > 1 and out.shape[0] >= 8:
             self._hops_pipelined(out, feat)
         else:
             self._hops_serial(out, feat)
         if self.global_attr:
             p = self.num_blocks() - 1
-            sums = self.ops.node_sums(out[:, :, :feat])
+            sums = col_sums if col_sums is not None else self.ops.node_sums(out[:, :, :feat])
             if self._dist:
                 if sums.is_cuda and dist.get_backend(self.group) == "gloo":
                     s_cpu = sums.cpu()
@@ -311,9 +314,11 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     d_h = reservoir.output_size
     pieces = spatial.n_chunks if pieces is None else pieces
     pieces = max(1, min(int(pieces), T // 8)) if x.is_cuda else 1
+    want_sums = spatial.global_attr and x.is_cuda and reservoir.produces_col_sums(x)
     if pieces <= 1 or not x.is_cuda:
-        reservoir.encode_into(x, out[:, :, :d_h], state)
-        return spatial.encode_into(out, d_h)
+        sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
+        reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
+        return spatial.encode_into(out, d_h, col_sums=sums)
     if state is None:
         state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
                             dtype=torch.float32, device=x.device)
@@ -326,11 +331,14 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     for j in range(pieces):
         t0, t1 = cuts[j], cuts[j + 1]
         with torch.cuda.stream(side):
-            reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state)
+            sums = torch.empty(t1 - t0, d_h, dtype=torch.float32, device=x.device) if want_sums else None
+            reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state, col_sums=sums)
             ready = torch.cuda.Event()
             ready.record(side)
         main.wait_event(ready)
-        spatial.encode_into(out[t0:t1], d_h)
+        if sums is not None:
+            sums.record_stream(main)
+        spatial.encode_into(out[t0:t1], d_h, col_sums=sums)
     for t in (x, out, state):
         t.record_stream(side)
     return out

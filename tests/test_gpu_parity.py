@@ -307,6 +307,20 @@ def test_fused_multi_layer_reservoir(n, f, r, L, act):
     wide = torch.zeros(t, n, 3 * L * r + 4, device="cuda")
     res.encode_into(xg, wide[:, :, :L * r])
     assert torch.equal(wide[:, :, :L * r], fused) and float(wide[:, :, L * r:].abs().max()) == 0.0
+    # column sums from the kernel's registers (global_attr block without a second pass over the
+    # states): same states bit for bit, sums == the fp64 sum over the nodes (n % 16 != 0: the last
+    # tile's padding lanes do not count), also chunk by chunk
+    sums = torch.full((t, L * r), float("nan"), device="cuda")
+    with_sums = torch.empty_like(fused)
+    assert res.produces_col_sums(xg)
+    res.encode_into(xg, with_sums, col_sums=sums)
+    assert torch.equal(with_sums, fused)
+    want = fused.double().sum(1)
+    assert float((sums.double() - want).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
+    state.zero_()
+    part = torch.empty(31, L * r, device="cuda")
+    res.encode_into(xg[:31], with_sums[:31], state, col_sums=part)
+    assert float((part.double() - want[:31]).abs().max()) <= 1e-5 * max(1.0, float(want.abs().max()))
 
 
 @pytest.mark.parametrize("act,f,r", [("tanh", 128, 256), ("relu", 128, 256), ("self_norm", 128, 256),
@@ -767,7 +781,7 @@ def test_scrambled_node_labels_take_the_fast_path():
     x = torch.randn(t, n, d)
     y = torch.full((t, n, d), float("nan"), device="cuda")
     op.propagate(x.cuda(), y)
-    assert op.last_kernel == "spmm_res" and op.tile_plan(d, torch.device("cuda")).reordered
+    assert op.last_kernel in ("spmm_res", "spmm_mix") and op.tile_plan(d, torch.device("cuda")).reordered
     y3 = torch.empty_like(y)
     op.propagate(x.cuda(), y3, force="blk")
     assert op.block_plan(d, torch.device("cuda")).reordered
@@ -1071,7 +1085,7 @@ def test_config_c3_at_its_own_shape():
     ops = spatial_operators(ei, ew, n)
     probe = torch.empty(1, n, 64, device="cuda")
     ops[0].propagate(out[:1, :, :64], probe)
-    assert ops[0].last_kernel in ("spmm_res", "spmm_pipe") and torch.equal(probe, out[:1, :, 64:128])
+    assert ops[0].last_kernel in ("spmm_mix", "spmm_res", "spmm_pipe") and torch.equal(probe, out[:1, :, 64:128])
     ref = O.sgp_encoder_forward(x[:48], ei, ew, layers_of(enc.reservoir), k, sparse=True)
     close(out[:48], ref)
     steps = torch.tensor([0, 47, 48, 1000, 2015], device="cuda")

@@ -407,6 +407,39 @@ int sgp_grouped_linear_f32(const float* X, int64_t x_row_stride, int64_t x_batch
                            float* out, int64_t out_row_stride,
                            int32_t n_rows, int32_t groups, int32_t ic, int32_t oc,
                            sgp_stream_t stream);
+/* Training the decoder (sgp_model.py:41-52 is a trained layer): the same forward that also writes the
+ * pre-activation values `pre[n_rows, groups*oc]` (NULL = sgp_grouped_linear_f32), and the three pieces
+ * of its backward pass.  With z = W x + b, y = act(z), incoming gradient dy:
+ *   sgp_grouped_linear_dact_f32       dz = dy * act'(z)            (dz, pre contiguous [n_rows, width])
+ *   sgp_grouped_linear_transpose_f32  W [groups*oc, ic] -> W^T laid out as the weight [groups*ic, oc] of
+ *                                     the layer with ic and oc exchanged: dx = that layer (packed with
+ *                                     sgp_grouped_linear_pack_f32, zero bias, act 0) applied to dz
+ *   sgp_grouped_linear_wgrad_f32      dW[g*oc + o, i] = sum_row dz[row, g*oc + o] * X_row[g*ic + i]
+ *                                     (rows as in the forward, IID gather included; fp32 MFMA with the
+ *                                     rows as contraction index, row slices meet through float atomics)
+ *   db = column sums of dz (sgp_node_mean_bcast_f32 with Y = NULL).
+ * Dropout(p) behind the activation (sgp_model.py:50; training mode only): `dropout_p` in [0, 1) and a
+ * 64-bit `seed` per call; element (row, column) is kept and scaled by 1 / (1 - p) when word 0 of
+ * Philox4x32-10(key = seed, counter = row * width + column) >= p * 2^32.  The forward applies the factor
+ * to `out` (not to `pre`), sgp_grouped_linear_dact_f32 with the same (p, seed) to dz. */
+int sgp_grouped_linear_fwd_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                               const int32_t* step, const int32_t* node,
+                               const float* w_packed, const float* bias, int32_t act,
+                               float* out, int64_t out_row_stride, float* pre,
+                               double dropout_p, uint64_t seed,
+                               int32_t n_rows, int32_t groups, int32_t ic, int32_t oc,
+                               sgp_stream_t stream);
+int sgp_grouped_linear_dact_f32(const float* dy, int64_t dy_row_stride, const float* pre, int32_t act,
+                                double dropout_p, uint64_t seed,
+                                float* dz, int64_t n_rows, int32_t width, sgp_stream_t stream);
+int sgp_grouped_linear_transpose_f32(const float* w, float* wt, int32_t groups, int32_t ic, int32_t oc,
+                                     sgp_stream_t stream);
+int sgp_grouped_linear_wgrad_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                                 const int32_t* step, const int32_t* node,
+                                 const float* dz, float* dw,
+                                 int32_t n_rows, int32_t groups, int32_t ic, int32_t oc,
+                                 sgp_stream_t stream);
+
 
 /* -------------------------------------------------------------- Timing -----
  * HIP-event helpers so that Python can time kernels on the stream they were

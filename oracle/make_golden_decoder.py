@@ -5,7 +5,9 @@ TEST INFRASTRUCTURE.  Imports the UNMODIFIED ``lib/nn/models/sgp_model.py`` unde
 this row -- ``StaticGraphEmbedding``, ``LinearReadout``, ``MLP``, ``ResidualMLP`` -- are stubbed
 with placeholders), builds the reference's ``SGPModel`` and records input / parameters / output
 of its ``input_encoder`` (``sgp_model.py:41-52``: Rearrange, grouped ``Conv1d(kernel_size=1,
-groups=order)``, Rearrange, activation, Dropout(0)).
+groups=order)``, Rearrange, activation, Dropout(0)) and, for the backward pass of that trained layer,
+the gradients ``autograd`` gives the reference module for a recorded cotangent ``gy``: ``gx`` (input),
+``gw`` / ``gb`` (``input_encoder.1.weight.grad`` / ``.bias.grad``).
 
     python oracle/make_golden_decoder.py    # writes tests/golden/g8_decoder_*.npz
 """
@@ -70,11 +72,19 @@ def main():
             y64 = model.input_encoder.double()(xin.double())
         model.input_encoder.float()
         conv = model.input_encoder[1]
+        # backward of the reference module itself: loss = <y, gy>
+        xg = xin.clone().requires_grad_(True)
+        yg = model.input_encoder(xg)
+        gy = torch.randn(*yg.shape, generator=torch.Generator().manual_seed(900 + idx))
+        model.input_encoder.zero_grad()
+        yg.backward(gy)
+        grads = dict(gy=gy.numpy(), gx=xg.grad.numpy(), gw=conv.weight.grad.numpy().copy(),
+                     gb=conv.bias.grad.numpy().copy())
         np.savez_compressed(os.path.join(GOLDEN, f"g8_decoder_{name}.npz"),
                             x=x.numpy(), y=y.numpy(), y64=y64.numpy(),
                             weight=conv.weight.detach().numpy(), bias=conv.bias.detach().numpy(),
                             cfg=np.array([f, order, hidden], dtype=np.int64), activation=np.array(act),
-                            seed=np.int64(800 + idx))
+                            seed=np.int64(800 + idx), **grads)
         print("wrote g8_decoder_" + name, tuple(x.shape), "->", tuple(y.shape), tuple(conv.weight.shape))
 
 

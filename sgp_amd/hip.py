@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("SGP_AMD_LIB") or os.path.join(_CSRC, "libsgp_amd.so")
 c_i32, c_i64, c_f32, c_f64, c_p = (ctypes.c_int32, ctypes.c_int64,
                                    ctypes.c_float, ctypes.c_double,
                                    ctypes.c_void_p)
+c_u64 = ctypes.c_uint64
 
 # name -> (restype, argtypes); mirrors include/sgp_amd.h one to one
 SIGNATURES = {
@@ -125,6 +126,13 @@ SIGNATURES = {
     "sgp_grouped_linear_pack_f32": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
     "sgp_grouped_linear_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
                                               c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_grouped_linear_fwd_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i32,
+                                                  c_p, c_i64, c_p, c_f64, c_u64,
+                                                  c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_grouped_linear_dact_f32": (ctypes.c_int, [c_p, c_i64, c_p, c_i32, c_f64, c_u64, c_p, c_i64, c_i32, c_p]),
+    "sgp_grouped_linear_transpose_f32": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
+    "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                                                    c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_event_create": (ctypes.c_int, [ctypes.POINTER(c_p)]),
     "sgp_event_destroy": (ctypes.c_int, [c_p]),
     "sgp_event_record": (ctypes.c_int, [c_p, c_p]),
@@ -654,26 +662,66 @@ def grouped_linear_pack(weight, groups):
     return packed
 
 
-@_on_device
-def grouped_linear(x2, packed, bias, groups, ic, oc, activation, step_index=None, node_index=None,
-                   source=None):
-    """rows [K, groups*ic] -> [K, groups*oc]; with (step_index, node_index) the rows are gathered
-    from ``source[T, N, groups*ic]`` instead of being read from ``x2``."""
-    lib = require_gpu()
+def _gl_rows(x2, step_index, node_index, source):
     if source is not None:
         xp, xrs, xbs = _view3(source, "source")
-        K = node_index.numel()
-        sp, np_ = step_index.data_ptr(), node_index.data_ptr()
-        dev = source.device
-    else:
-        if x2.dim() != 2 or x2.stride(1) != 1:
-            raise ValueError("grouped_linear: rows must be a 2-D view with unit feature stride")
-        xp, xrs, xbs, K, sp, np_, dev = x2.data_ptr(), x2.stride(0), 0, x2.shape[0], None, None, x2.device
+        return xp, xrs, xbs, node_index.numel(), step_index.data_ptr(), node_index.data_ptr(), source.device
+    if x2.dim() != 2 or x2.stride(1) != 1:
+        raise ValueError("grouped_linear: rows must be a 2-D view with unit feature stride")
+    return x2.data_ptr(), x2.stride(0), 0, x2.shape[0], None, None, x2.device
+
+
+@_on_device
+def grouped_linear(x2, packed, bias, groups, ic, oc, activation, step_index=None, node_index=None,
+                   source=None, want_pre=False, dropout_p=0., seed=0):
+    """rows [K, groups*ic] -> [K, groups*oc]; with (step_index, node_index) the rows are gathered
+    from ``source[T, N, groups*ic]`` instead of being read from ``x2``.  ``want_pre``: also return the
+    pre-activation values (for the backward pass); ``dropout_p`` / ``seed``: Philox dropout mask."""
+    lib = require_gpu()
+    xp, xrs, xbs, K, sp, np_, dev = _gl_rows(x2, step_index, node_index, source)
     out = torch.empty(K, groups * oc, dtype=torch.float32, device=dev)
-    _check(lib.sgp_grouped_linear_f32(xp, xrs, xbs, sp, np_, packed.data_ptr(), bias.data_ptr(),
-                                      GL_ACT_CODES[activation], out.data_ptr(), out.stride(0),
-                                      K, groups, ic, oc, _stream(out)), "sgp_grouped_linear_f32")
-    return out
+    pre = torch.empty(K, groups * oc, dtype=torch.float32, device=dev) if want_pre else None
+    _check(lib.sgp_grouped_linear_fwd_f32(xp, xrs, xbs, sp, np_, packed.data_ptr(), bias.data_ptr(),
+                                          GL_ACT_CODES[activation], out.data_ptr(), out.stride(0),
+                                          pre.data_ptr() if want_pre else None, float(dropout_p), int(seed),
+                                          K, groups, ic, oc, _stream(out)), "sgp_grouped_linear_fwd_f32")
+    return (out, pre) if want_pre else out
+
+
+@_on_device
+def grouped_linear_dact(dy, pre, activation, dropout_p=0., seed=0):
+    """dz = dy * dropout factor * act'(pre) (contiguous [K, width])."""
+    lib = require_gpu()
+    if dy.dim() != 2 or dy.stride(1) != 1:
+        dy = dy.contiguous()
+    dz = torch.empty_like(pre)
+    _check(lib.sgp_grouped_linear_dact_f32(dy.data_ptr(), dy.stride(0), pre.data_ptr(), GL_ACT_CODES[activation],
+                                           float(dropout_p), int(seed), dz.data_ptr(), pre.shape[0], pre.shape[1],
+                                           _stream(dz)), "sgp_grouped_linear_dact_f32")
+    return dz
+
+
+@_on_device
+def grouped_linear_transpose(weight, groups):
+    """Conv1d weight [groups*oc, ic(, 1)] -> the weight [groups*ic, oc] of the transposed grouped layer."""
+    lib = require_gpu()
+    w = weight.reshape(weight.shape[0], -1).contiguous().float()
+    oc, ic = w.shape[0] // groups, w.shape[1]
+    wt = torch.empty(groups * ic, oc, dtype=torch.float32, device=w.device)
+    _check(lib.sgp_grouped_linear_transpose_f32(w.data_ptr(), wt.data_ptr(), groups, ic, oc, _stream(w)),
+           "sgp_grouped_linear_transpose_f32")
+    return wt
+
+
+@_on_device
+def grouped_linear_wgrad(x2, dz, groups, ic, oc, step_index=None, node_index=None, source=None):
+    """dW[groups*oc, ic] = sum over rows of dz[row, g*oc + o] * x[row, g*ic + i]."""
+    lib = require_gpu()
+    xp, xrs, xbs, K, sp, np_, dev = _gl_rows(x2, step_index, node_index, source)
+    dw = torch.empty(groups * oc, ic, dtype=torch.float32, device=dev)
+    _check(lib.sgp_grouped_linear_wgrad_f32(xp, xrs, xbs, sp, np_, dz.data_ptr(), dw.data_ptr(),
+                                            K, groups, ic, oc, _stream(dw)), "sgp_grouped_linear_wgrad_f32")
+    return dw
 
 
 class Event:

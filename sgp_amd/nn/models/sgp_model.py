@@ -11,13 +11,63 @@ the first hidden activations.
 
 Parameters keep the reference's names and shapes (``weight [out_channels, input_size / order, 1]``,
 ``bias [out_channels]``, initialised by ``nn.Conv1d`` itself, so ``load_state_dict`` of the
-reference's ``input_encoder.1`` works).  Forward only: training the decoder is outside this
-package's path (out of scope).
+reference's ``input_encoder.1`` works).
+
+The reference trains this layer (Lightning optimiser loop around ``sgp_model.py:41-52``), so it has a
+backward pass: ``_GroupedLinearFn`` is an ``autograd.Function`` whose pieces are HIP kernels too --
+``dz = dy * dropout * act'(z)``, ``dx`` = the same forward kernel on ``dz`` with the transposed
+grouped weight, ``dW`` on the fp32 matrix cores with the rows as contraction index, ``db`` = column
+sums of ``dz``.  ``Dropout(p)`` (``sgp_model.py:50``) is a Philox4x32-10 mask keyed by a per-call seed
+drawn from torch's generator and recomputed, not stored, by the backward pass; like ``nn.Dropout`` it
+is the identity in ``eval()`` mode.  (The reference's CPU / CUDA dropout streams differ from each
+other too: the mask is not part of the parity contract, its rate, scale and forward / backward
+consistency are -- tests/test_gpu_parity.py.)
 """
 import torch
 from torch import nn
 
 from ... import hip
+
+
+class _GroupedLinearFn(torch.autograd.Function):
+    """y = dropout(act(grouped_linear(rows))) with rows either ``x2[K, groups*ic]`` or gathered from
+    ``source[step, node]``; gradients for x2 (not for a gathered source: the embedding is data),
+    weight and bias."""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias, source, step, node, groups, activation, p, seed):
+        w2 = weight.reshape(weight.shape[0], -1)
+        oc, ic = w2.shape[0] // groups, w2.shape[1]
+        dev = x2.device if x2 is not None else source.device
+        wd = w2.detach().to(dev, torch.float32)
+        packed = hip.grouped_linear_pack(wd, groups)
+        bd = bias.detach().to(dev, torch.float32).contiguous()
+        y, pre = hip.grouped_linear(x2, packed, bd, groups, ic, oc, activation, step_index=step,
+                                    node_index=node, source=source, want_pre=True, dropout_p=p, seed=seed)
+        ctx.save_for_backward(x2 if x2 is not None else source, wd, pre, step, node)
+        ctx.cfg = (groups, ic, oc, activation, p, seed, x2 is None, weight.shape, weight.device, bias.device)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, wd, pre, step, node = ctx.saved_tensors
+        groups, ic, oc, activation, p, seed, sampled, wshape, wdev, bdev = ctx.cfg
+        dz = hip.grouped_linear_dact(dy, pre, activation, dropout_p=p, seed=seed)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0] and not sampled:
+            wt = hip.grouped_linear_pack(hip.grouped_linear_transpose(wd, groups), groups)
+            zero = torch.zeros(groups * ic, dtype=torch.float32, device=dz.device)
+            dx = hip.grouped_linear(dz, wt, zero, groups, oc, ic, None)
+        if ctx.needs_input_grad[1]:
+            if sampled:
+                dw = hip.grouped_linear_wgrad(None, dz, groups, ic, oc, step_index=step, node_index=node,
+                                              source=rows)
+            else:
+                dw = hip.grouped_linear_wgrad(rows, dz, groups, ic, oc)
+            dw = dw.reshape(wshape).to(wdev)
+        if ctx.needs_input_grad[2]:
+            db = hip.node_sums(dz[None])[0].to(bdev)
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
 class SGPInputEncoder(nn.Module):
@@ -27,8 +77,9 @@ class SGPInputEncoder(nn.Module):
             raise ValueError("in_channels must be divisible by groups")      # nn.Conv1d's own check
         if activation not in hip.GL_ACT_CODES:
             raise ValueError(f"Activation '{activation}' not valid.")
-        if dropout:
-            raise NotImplementedError("forward-only layer: dropout must be 0")
+        if not 0. <= float(dropout) < 1.:
+            raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")
+        self.dropout = float(dropout)
         self.input_size, self.order = int(input_size), int(order)
         self.out_channels = hidden_size - hidden_size % order               # sgp_model.py:41
         if self.out_channels <= 0:
@@ -68,10 +119,25 @@ class SGPInputEncoder(nn.Module):
         rows = x.reshape(-1, self.input_size)
         if rows.stride(1) != 1:
             rows = rows.contiguous()
-        packed, bias = self._device_params(x.device)
-        y = hip.grouped_linear(rows, packed, bias, self.order, self._ic, self._oc, self.activation)
+        if self._needs_graph(rows):
+            y = _GroupedLinearFn.apply(rows, self.weight, self.bias, None, None, None, self.order,
+                                       self.activation, *self._dropout_args())
+        else:
+            packed, bias = self._device_params(x.device)
+            y = hip.grouped_linear(rows, packed, bias, self.order, self._ic, self._oc, self.activation)
         y = y.reshape(x.shape[0], x.shape[1], self.out_channels)
         return y.cpu() if on_cpu else y
+
+    def _dropout_args(self):
+        """(p, seed): a fresh 63-bit seed from torch's default generator per training-mode call."""
+        if not (self.training and self.dropout > 0.):
+            return 0., 0
+        return self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item())
+
+    def _needs_graph(self, rows=None):
+        grad = torch.is_grad_enabled() and (self.weight.requires_grad or self.bias.requires_grad or
+                                            (rows is not None and rows.requires_grad))
+        return grad or (self.training and self.dropout > 0.)
 
     def forward_sampled(self, embedding, step_index, node_index):
         """Rows ``embedding[step_index[k], node_index[k], :]`` -> [K, 1, out_channels] without
@@ -79,9 +145,13 @@ class SGPInputEncoder(nn.Module):
         hip.require_gpu()
         if embedding.dim() != 3 or embedding.shape[-1] != self.input_size or not embedding.is_cuda:
             raise ValueError("embedding must be a CUDA tensor [T, N, input_size]")
-        packed, bias = self._device_params(embedding.device)
         st = step_index.to(embedding.device, torch.int32)
         nd = node_index.to(embedding.device, torch.int32)
-        y = hip.grouped_linear(None, packed, bias, self.order, self._ic, self._oc, self.activation,
-                               step_index=st, node_index=nd, source=embedding)
+        if self._needs_graph():
+            y = _GroupedLinearFn.apply(None, self.weight, self.bias, embedding.detach(), st, nd, self.order,
+                                       self.activation, *self._dropout_args())
+        else:
+            packed, bias = self._device_params(embedding.device)
+            y = hip.grouped_linear(None, packed, bias, self.order, self._ic, self._oc, self.activation,
+                                   step_index=st, node_index=nd, source=embedding)
         return y[:, None, :]

@@ -748,6 +748,94 @@ def test_decoder_input_encoder_matches_reference(name):
     close(ys[:, 0], torch.from_numpy(z["y"])[si, ni])
 
 
+@pytest.mark.parametrize("name", golden_files("g8_decoder_"))
+def test_decoder_input_encoder_backward_matches_reference(name):
+    """Backward pass of the trained first decoder layer (sgp_model.py:41-52): input / weight / bias
+    gradients of SGPInputEncoder (HIP kernels behind an autograd.Function) == the gradients autograd
+    gave the reference SGPModel.input_encoder for the recorded cotangent; also through the fused IID
+    gather (weight / bias gradients) and against the written-out oracle in fp64."""
+    from sgp_amd.nn.models import SGPInputEncoder
+    z = load(name)
+    f, order, hidden = [int(v) for v in z["cfg"]]
+    act = str(z["activation"])
+    enc = SGPInputEncoder(f, order, hidden, activation=act)
+    enc.weight.data.copy_(torch.from_numpy(z["weight"])); enc.bias.data.copy_(torch.from_numpy(z["bias"]))
+    enc = enc.cuda()
+    x = torch.from_numpy(z["x"])
+    xin = (x[:, -1] if x.dim() == 4 else x).cuda().requires_grad_(True)
+    gy = torch.from_numpy(z["gy"]).cuda()
+    y = enc(xin)
+    close(y, z["y"])
+    y.backward(gy)
+
+    def gclose(a, ref):           # 1e-5 relative to the gradient's scale (sums over the batch rows)
+        ref = torch.as_tensor(ref)
+        s = float(ref.abs().max())
+        assert torch.allclose(a.detach().cpu(), ref, rtol=1e-5, atol=1e-5 * max(s, 1e-30)), \
+            f"max abs {float((a.detach().cpu() - ref).abs().max()):.3e} at scale {s:.3e}"
+        assert O.rel_fro(a.detach().cpu(), ref) <= 1e-5
+    gclose(xin.grad, z["gx"]); gclose(enc.weight.grad, z["gw"]); gclose(enc.bias.grad, z["gb"])
+    o64 = O.decoder_input_encoder_grads(x.double(), torch.from_numpy(z["weight"]).double(),
+                                        torch.from_numpy(z["bias"]).double(), order, act, gy.cpu().double())
+    for got, ref in zip((xin.grad, enc.weight.grad, enc.bias.grad), o64):
+        gclose(got, ref.float())
+    # accumulation into existing .grad and a non-contiguous cotangent
+    y2 = enc(xin.detach())
+    wide = torch.zeros(*gy.shape[:-1], gy.shape[-1] + 3, device="cuda")
+    wide[..., 1:1 + gy.shape[-1]] = gy
+    y2.backward(wide[..., 1:1 + gy.shape[-1]])
+    gclose(enc.weight.grad, 2 * z["gw"]); gclose(enc.bias.grad, 2 * z["gb"])
+    # fused with the IID gather: every (b, n) row exactly once, in a shuffled order
+    enc.zero_grad()
+    b, n = xin.shape[0], xin.shape[1]
+    perm = torch.randperm(b * n)
+    si, ni = perm // n, perm % n
+    ys = enc.forward_sampled(xin.detach().contiguous(), si, ni)
+    ys.backward(gy[si, ni][:, None, :])
+    gclose(enc.weight.grad, z["gw"]); gclose(enc.bias.grad, z["gb"])
+    # no graph, no extra work: inference calls return plain tensors
+    with torch.no_grad():
+        assert not enc(xin).requires_grad
+
+
+def test_decoder_dropout_mask_is_shared_by_forward_and_backward():
+    """Dropout(p) behind the activation (sgp_model.py:50): identity in eval mode; in training mode
+    the kept fraction is 1 - p, kept values are scaled by 1 / (1 - p), a new mask per call, and the
+    backward pass uses the SAME mask (recomputed from the seed): dropped units get no gradient."""
+    from sgp_amd.nn.models import SGPInputEncoder
+    torch.manual_seed(5)
+    f, order, hidden, p = 256, 4, 128, 0.3
+    enc = SGPInputEncoder(f, order, hidden, activation=None, dropout=p).cuda()
+    ref = SGPInputEncoder(f, order, hidden, activation=None)
+    ref.load_state_dict(enc.state_dict()); ref = ref.cuda()
+    x = torch.randn(300, 7, f, device="cuda")
+    enc.eval()
+    with torch.no_grad():
+        base = ref(x)
+        assert torch.equal(enc(x), base)
+    enc.train()
+    y = enc(x)
+    kept = y != 0
+    frac = float(kept.float().mean())
+    assert abs(frac - (1 - p)) < 0.01, frac
+    close(y[kept], (base / (1 - p))[kept])
+    y2 = enc(x)
+    assert float(((y2 != 0) ^ kept).float().mean()) > 0.2          # a different mask
+    # linear layer: d<y, 1>/d bias[c] = (number of kept entries in column c) / (1 - p)
+    enc.zero_grad()
+    y = enc(x)
+    kept = (y != 0).reshape(-1, y.shape[-1])
+    y.sum().backward()
+    close(enc.bias.grad, kept.float().sum(0) / (1 - p), rtol=1e-5, atol=1e-3)
+    # identity activation: dW = (mask * 1 / (1 - p))^T x
+    xg = x.reshape(-1, order, f // order)
+    m = kept.float().reshape(-1, order, hidden // order) / (1 - p)
+    gw = torch.einsum("rgo,rgi->goi", m.double(), xg.double()).reshape(enc.weight.shape)
+    assert O.rel_fro(enc.weight.grad.cpu().double(), gw.cpu()) <= 1e-5
+    with pytest.raises(ValueError):
+        SGPInputEncoder(f, order, hidden, dropout=1.0)
+
+
 @pytest.mark.parametrize("name", golden_files("g9_onthefly_"))
 def test_onthefly_supports_match_reference(name):
     """sgp_amd.dataloader.apply_supports (supports applied on the GPU, blocks written in place)

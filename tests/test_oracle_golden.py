@@ -182,6 +182,13 @@ def test_decoder_input_encoder(name):
     close(y, z["y"])
     y64 = O.decoder_input_encoder(x.double(), w.double(), b.double(), order, str(z["activation"]))
     close(y64, z["y64"], rtol=1e-10, atol=1e-10)
+    # backward pass of the trained layer: oracle (written out) == the reference module's autograd
+    gx, gw, gb = O.decoder_input_encoder_grads(x.double(), w.double(), b.double(), order, str(z["activation"]),
+                                               torch.from_numpy(z["gy"]).double())
+    sc = lambda a: float(np.abs(a).max())
+    close(gx.float(), z["gx"], rtol=1e-5, atol=1e-5 * sc(z["gx"]))
+    close(gw.float(), z["gw"], rtol=1e-5, atol=1e-5 * sc(z["gw"]))
+    close(gb.float(), z["gb"], rtol=1e-5, atol=1e-5 * sc(z["gb"]))
 
 
 # ------------------------------------------------------------------ f3: on-the-fly supports

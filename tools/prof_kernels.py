@@ -30,6 +30,14 @@ def main():
         for _ in range(3):
             res.encode_into(xin, out)
         torch.cuda.synchronize()
+    if what == "res256":                       # C5's layer: F = 128, R = 256 (weights streamed through LDS)
+        torch.manual_seed(0)
+        res = sgp_amd.Reservoir(128, 256)
+        xin = torch.randn(T, N, 128, device="cuda")
+        out = torch.empty(T, N, 256, device="cuda")
+        for _ in range(3):
+            res.encode_into(xin, out)
+        torch.cuda.synchronize()
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@
 
 #pragma once
 #include "common.h"
+#include <stdlib.h>
 
 namespace sgp_res {
 using sgp::f32x4;
@@ -89,10 +90,22 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
     const int lane = threadIdx.x & 63;
     const int n_in = lane & 15, q = lane >> 4;
     // tiles are dealt to waves as evenly as possible: wave w owns [w*n/W, (w+1)*n/W), 0..NT tiles
-    const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    const int tile0 = (int)((long long)wave * a.n_tiles / n_waves);
-    const int tile1 = (int)((long long)(wave + 1) * a.n_tiles / n_waves);
+    int tile0, tile1;
+    if (a.tiles_per_wave > 0) {
+        // exact deal (16-wave workgroups, one per CU): waves w, w + 4, w + 8, w + 12 share a SIMD and
+        // together own `per` consecutive tiles, as evenly as NT allows -- every SIMD of the chip carries
+        // the same number of tiles (launch_layer; the tiles beyond 1024 x per go to the split-J kernel)
+        const int per = a.tiles_per_wave;
+        const int wl = threadIdx.x >> 6, c = wl & 3, k = wl >> 2;
+        const int base = per >> 2, extra = per & 3;
+        tile0 = (blockIdx.x * 4 + c) * per + k * base + min(k, extra);
+        tile1 = min(tile0 + base + (k < extra ? 1 : 0), a.n_tiles);
+    } else {
+        const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int n_waves = gridDim.x * (blockDim.x >> 6);
+        tile0 = (int)((long long)wave * a.n_tiles / n_waves);
+        tile1 = (int)((long long)(wave + 1) * a.n_tiles / n_waves);
+    }
     if (tile0 >= tile1) return;
 
     int node[NT];
@@ -712,7 +725,10 @@ int launch_layer(ResArgs a, hipStream_t s) {
     // Large problems: a wave count that is a multiple of 1024 SIMDs, tiles dealt evenly,
     // so every SIMD carries the same number of waves and (almost) of tiles.
     int wpw = 1, grid = a.n_tiles;
-    if (a.n_tiles > 1024) {
+    if (a.tiles_per_wave > 0) {                  // exact deal: one 16-wave workgroup per CU
+        wpw = 16;
+        grid = 256;
+    } else if (a.n_tiles > 1024) {
         const int rounds = (a.n_tiles + 1024 * NT - 1) / (1024 * NT);
         const int n_waves = 1024 * rounds;
         // Narrow reservoirs (<= 128 VGPRs): ONE 16-wave workgroup per CU, so that the waves that
@@ -743,21 +759,56 @@ int launch_layer(ResArgs a, hipStream_t s) {
 
 template <int JT, int NKX> int launch_stream_ool(const ResArgs& a, hipStream_t s);   // reservoir_stream.hip
 
+// experiment knobs (read once): SGP_RES_SPLITJ_MAX = largest tile count served by the split-J kernel
+// alone, SGP_RES_TAIL = 0 disables the exact deal + split-J tail of large problems
+inline int res_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+template <int JT, int NKX>
+int launch_splitj(const ResArgs& a, int n_tiles, hipStream_t s) {
+    ResArgs b = a;
+    b.n_tiles = n_tiles;
+    const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+    auto kern = ov ? reservoir_layer_splitj<JT, NKX, true> : reservoir_layer_splitj<JT, NKX, false>;
+    const int bytes = (int)splitj_lds_bytes<JT, NKX>();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), (size_t)bytes, s, b);
+    return sgp::check_launch("reservoir_layer_splitj");
+}
+
 template <int JT, int NKX>
 int launch_nt(const ResArgs& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
-    if constexpr (JT % 4 == 0 && splitj_lds_bytes<JT, NKX>() <= kLdsLimit) {
-        if (n_tiles <= 512) {                       // up to 2 workgroups per CU: latency-bound regime
-            ResArgs b = a;
-            b.n_tiles = n_tiles;
-            const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
-            auto kern = ov ? reservoir_layer_splitj<JT, NKX, true> : reservoir_layer_splitj<JT, NKX, false>;
-            const int bytes = (int)splitj_lds_bytes<JT, NKX>();
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
-            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), (size_t)bytes, s, b);
-            return sgp::check_launch("reservoir_layer_splitj");
+    constexpr bool kSplitj = JT % 4 == 0 && splitj_lds_bytes<JT, NKX>() <= kLdsLimit;
+    if constexpr (kSplitj) {
+        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 512);
+        if (n_tiles <= splitj_max)                  // a few workgroups per CU: latency-bound regime
+            return launch_splitj<JT, NKX>(a, n_tiles, s);
+    }
+    if constexpr (JT <= 4 && kSplitj) {
+        // Large N: 1024 SIMDs x `per` tiles exactly (reservoir_layer's exact deal), and the L < 1024
+        // tiles that are left as a split-J tail: 4 SIMDs share a tile there, a workgroup steps through
+        // T in ~0.7 us per step -- a fraction of the per + 1'th tile that the busiest SIMDs would
+        // otherwise carry while the others idle (N = 100k: 6250 tiles = 6.1 per SIMD, 7 on the busiest).
+        static const int tail = res_env("SGP_RES_TAIL", 1);
+        const int per = n_tiles / 1024, left = n_tiles - per * 1024;
+        if (tail && per >= 1 && per <= 8 && left <= 512) {
+            ResArgs m = a;
+            m.N = left ? per * 1024 * 16 : a.N;
+            m.tiles_per_wave = per;
+            int rc = per > 4 ? launch_layer<JT, NKX, 2>(m, s) : launch_layer<JT, NKX, 1>(m, s);
+            if (rc || !left) return rc;
+            ResArgs t = a;
+            const long long n0 = (long long)per * 1024 * 16;
+            t.x = a.x + n0 * a.xrs;
+            t.out = a.out + n0 * a.ors;
+            if (a.h_state) t.h_state = a.h_state + n0 * a.R;
+            t.N = a.N - (int)n0;
+            return launch_splitj<JT, NKX>(t, left, s);
         }
     }
     if constexpr (JT <= 4) {

@@ -199,7 +199,7 @@ class SGPEncoder(nn.Module):
     stream_threshold_bytes = 256 << 20
     stream_chunk_bytes = 1 << 30          # embedding bytes per time chunk of the pipelined path
 
-    def encode_streamed(self, x, ops, t_chunk):
+    def encode_streamed(self, x, ops, t_chunk, out=None):
         """Host tensor x[T, N, F] -> host tensor [T, N, D_out], ``t_chunk`` steps at a time,
         transfers overlapped with the compute (the drivers hand over host tensors,
         lib/utils.py:24-31): two device buffers per direction, H2D of chunk i+1 (through a pinned
@@ -211,7 +211,13 @@ class SGPEncoder(nn.Module):
         independent per time step, so the result is bit-identical to a single pass.  This is
         also how embeddings larger than the 288 GB of HBM (BASELINE config C5: 629 GB) or than
         the free memory are produced.  The returned tensor is ordinary (pageable) host memory:
-        the reference's drivers fork DataLoader workers that inherit it copy-on-write."""
+        the reference's drivers fork DataLoader workers that inherit it copy-on-write.
+
+        ``out``: a caller-supplied contiguous float32 host tensor ``[T, N, D_out]`` to fill instead
+        of a fresh one.  A FRESH result tensor costs this host a page fault + zeroing per page
+        (11-13 GB/s) -- more than the PCIe transfer; a tensor that is re-used between
+        calls (or was touched before) skips that, and a pinned one (``pin_memory=True``) is written
+        by the D2H copies directly, without the registration thread."""
         hip.require_gpu()
         T, N, F = x.shape
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -219,9 +225,14 @@ class SGPEncoder(nn.Module):
         d_h, D = L * R, self.output_size
         tc = max(1, min(int(t_chunk), T))
         starts = list(range(0, T, tc))
-        out = torch.empty(T, N, D, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(T, N, D, dtype=torch.float32)
+        elif (out.is_cuda or out.dtype != torch.float32 or tuple(out.shape) != (T, N, D)
+              or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous float32 host tensor of shape {(T, N, D)}")
         if T == 0:
             return out
+        out_pinned = out.is_pinned()
         state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
         nbuf = 2 if len(starts) > 1 else 1
         xin = [torch.empty(tc, N, F, dtype=torch.float32, device=dev) for _ in range(nbuf)]
@@ -229,7 +240,7 @@ class SGPEncoder(nn.Module):
         x_pinned = x.is_pinned() and x.dtype == torch.float32
         pin_in = None if x_pinned else [torch.empty(tc, N, F, dtype=torch.float32, pin_memory=True)
                                         for _ in range(nbuf)]
-        sink = _RegisteredSink(out) if self.register_output else None
+        sink = _RegisteredSink(out) if self.register_output and not out_pinned else None
         pin_out = [None] * nbuf                                  # pinned bounce slots: only if needed
         main = torch.cuda.current_stream(dev)
         h2d, d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
@@ -262,7 +273,7 @@ class SGPEncoder(nn.Module):
             pinned slot that ``drain`` copies out."""
             s, t0 = i % nbuf, starts[i]
             n = min(tc, T - t0)
-            direct = sink is not None and sink.wait((t0 + n) * row_bytes)
+            direct = out_pinned or (sink is not None and sink.wait((t0 + n) * row_bytes))
             if not direct and pin_out[s] is None:
                 pin_out[s] = torch.empty(tc, N, D, dtype=torch.float32, pin_memory=True)
             bounced[s] = not direct
@@ -271,7 +282,9 @@ class SGPEncoder(nn.Module):
                 if direct:
                     src = buf[s][:n].reshape(-1)
                     e0 = t0 * (row_bytes // 4)
-                    for a, b in sink.pieces(t0 * row_bytes, (t0 + n) * row_bytes):
+                    cuts = [(t0 * row_bytes, (t0 + n) * row_bytes)] if out_pinned else \
+                        sink.pieces(t0 * row_bytes, (t0 + n) * row_bytes)
+                    for a, b in cuts:
                         out_flat[a // 4:b // 4].copy_(src[a // 4 - e0:b // 4 - e0], non_blocking=True)
                 else:
                     pin_out[s][:n].copy_(buf[s][:n], non_blocking=True)
@@ -315,9 +328,10 @@ class SGPEncoder(nn.Module):
     # D2H straight into the (registered) result tensor; False = pinned bounce slots + host memcpy
     register_output = True
 
-    def forward(self, x, edge_index, edge_weight, return_device=False):
+    def forward(self, x, edge_index, edge_weight, return_device=False, out=None):
         # x : [t n f]; ``return_device=True`` keeps the embedding of a host input on the GPU
-        # (the next row f1 consumes it there: sgp_amd.datasets.IIDDataset)
+        # (the next row f1 consumes it there: sgp_amd.datasets.IIDDataset); ``out``: host tensor
+        # [t, n, d_out] to fill (host inputs only; see encode_streamed)
         dev = x.device
         ops = self.sgp_encoder.operators(x.size(-2), edge_index, edge_weight)
         xg = x.float()
@@ -335,8 +349,12 @@ class SGPEncoder(nn.Module):
                 # propagation kernels at their full-size rates
                 t_chunk = max(1, min(budget // (2 * per_step),
                                      max(32, self.stream_chunk_bytes // max(1, N * self.output_size * 4))))
-                return self.encode_streamed(xg, ops, t_chunk)
+                return self.encode_streamed(xg, ops, t_chunk, out=out)
+            if out is not None:
+                return self.encode_streamed(xg, ops, T, out=out)
             xg = xg.cuda()
+        if out is not None:
+            raise ValueError("out= is for host inputs (a device input returns a device tensor)")
         if xg.stride(2) != 1:
             xg = xg.contiguous()
         return self.encode_device(xg, ops).to(dev)

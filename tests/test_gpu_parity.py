@@ -1248,6 +1248,21 @@ def test_pipelined_host_streaming_paths():
     auto = enc(x, ei, ew)
     assert not auto.is_cuda and torch.equal(auto, full)
     assert enc(x, ei, ew, return_device=True).is_cuda
+    # caller-supplied result tensors: pageable (re-used between calls) and pinned (direct D2H)
+    for mk in (lambda: torch.full(full.shape, float("nan")),
+               lambda: torch.full(full.shape, float("nan")).pin_memory()):
+        o = mk()
+        r = enc.encode_streamed(x, ops, 8, out=o)
+        assert r.data_ptr() == o.data_ptr() and torch.equal(o, full)
+        o.fill_(float("nan"))
+        assert enc(x, ei, ew, out=o).data_ptr() == o.data_ptr() and torch.equal(o, full)
+    enc.stream_threshold_bytes = 1 << 40                     # small input, out= still honoured
+    o = torch.empty_like(full)
+    assert enc(x, ei, ew, out=o).data_ptr() == o.data_ptr() and torch.equal(o, full)
+    with pytest.raises(ValueError):
+        enc.encode_streamed(x, ops, 8, out=torch.empty(t, n, 3))
+    with pytest.raises(ValueError):
+        enc(x.cuda(), ei, ew, out=torch.empty_like(full))
 
 
 # ------------------------------------------------------------------ legacy API rows (R6, S7) and S2's flags

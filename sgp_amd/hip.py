@@ -144,10 +144,13 @@ ACT_CODES = {"tanh": 0, "relu": 1, "self_norm": 2, "identity": 3}
 _lib = None
 
 
-def build(jobs=8, verbose=False):
-    """Compile every HIP source for gfx950 into ``csrc/libsgp_amd.so`` (in-tree)."""
-    out = subprocess.run(["make", "-C", _CSRC, f"-j{jobs}"], capture_output=True,
-                         text=True)
+def build(jobs=8, verbose=False, asan=False):
+    """Compile every HIP source for gfx950 into ``csrc/libsgp_amd.so`` (in-tree).  ``asan=True`` also
+    builds ``csrc/build_asan/libsgp_amd_asan.so`` -- the host halves under AddressSanitizer -- which
+    ``tests/test_abi.py::test_host_asan_build`` drives (argument checks of every entry point, planner
+    output through the hop kernels' launch arithmetic)."""
+    out = subprocess.run(["make", "-C", _CSRC, f"-j{jobs}"] + (["libsgp_amd.so", "asan"] if asan else []),
+                         capture_output=True, text=True)
     if verbose or out.returncode:
         print(out.stdout[-4000:])
         print(out.stderr[-4000:])

@@ -74,7 +74,11 @@ def test_host_asan_build():
     import subprocess
     import sys
     if not os.path.exists(ASAN_LIB):
-        pytest.skip("build it with `make -C sgp_amd/csrc asan` (about a minute)")
+        # built on demand (about 90 s on 8 cores); a toolchain that cannot build it skips the test
+        r = subprocess.run(["make", "-C", os.path.join(ROOT, "sgp_amd", "csrc"), "-j8", "asan"],
+                           capture_output=True, text=True, timeout=1500)
+        if r.returncode != 0 or not os.path.exists(ASAN_LIB):
+            pytest.skip("ASan build failed here: " + r.stderr[-300:])
     rt = sorted(glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so"))
     if not rt:
         pytest.skip("no ASan runtime in this image")
@@ -101,7 +105,60 @@ assert isinstance(lib.sgp_last_error(), bytes)
 for f, r, l in ((3, 16, 8), (64, 64, 2), (300, 64, 2), (3, 16, 40)):
     lib.sgp_reservoir_fused_supported(f, r, l); lib.sgp_reservoir_fused_workspace_bytes(f, r, l)
     lib.sgp_reservoir_workspace_bytes(f, r); lib.sgp_gesn_workspace_bytes(100, r, l)
-print("asan-ok", n_calls)
+# ---- launch arithmetic with VALID plans: the planners' arrays (host memory) and host operand buffers go
+# through every hop entry point; the host halves choose time chunks, grids, LDS sizes and template
+# variants from them.  Without a GPU the launch itself fails cleanly (an error code) after that
+# arithmetic; with one the host pointers must not reach a kernel, so this part is skipped.
+import torch
+n_plans = 0
+if not torch.cuda.is_available():
+    from sgp_amd import graph, synthetic
+    for n, k, feat, batch in ((700, 20, 64, 40), (64, 5, 64, 3), (3000, 40, 128, 700)):
+        ei, ew, _ = synthetic.knn_graph(n, k, seed=n)
+        op = graph.ShiftOperator.from_edges(ei, ew, n)
+        cpu = torch.device("cpu")
+        plan = op.tile_plan(feat, cpu, tall=False)
+        x = torch.zeros(batch, n, feat); y = torch.zeros(batch, n, feat)
+        P = lambda t: t.data_ptr()
+        rowptr, col, val = op.csr()
+        rp32, c32 = rowptr.int(), col.int()
+        rc = lib.sgp_spmm_csr_f32(P(rp32), P(c32), P(val), P(x), feat, n * feat, None, 0, 0, 0,
+                                  P(y), feat, n * feat, n, n, batch, feat, None)
+        assert isinstance(rc, int) and rc != 0
+        n_plans += 1
+        if plan is None or plan.pipe is None:
+            continue
+        ps = plan.pipe
+        common = (P(x), feat, n * feat, None, 0, 0, 0, P(y), feat, n * feat, plan.n_rows, n, batch, feat, None)
+        for fn in (lib.sgp_spmm_pipe_f32, lib.sgp_spmm_res_f32):
+            rc = fn(P(ps["uptr"]), P(ps["ucol"]), P(ps["usplit"]), P(ps["gptr"]), P(ps["gsup"]), P(ps["gidx"]),
+                    P(ps["gw"]), P(ps["rowmap"]), plan.n_tiles, ps["max_union"], ps["max_tile_quads"], *common)
+            assert isinstance(rc, int) and rc != 0          # no device: an error, not a crash
+            n_plans += 1
+        mp = op.mix_plan(feat, cpu, strict=False)
+        if mp is not None:
+            rc = lib.sgp_spmm_mix_f32(P(mp.uptr), P(mp.ucol), P(mp.usplit), P(mp.gptr), P(mp.gsup), P(mp.gidx),
+                                      P(mp.gw), P(mp.rowmap), P(mp.dptr), P(mp.didx), P(mp.dw),
+                                      mp.n_tiles, mp.max_union, mp.max_dense, *common)
+            assert isinstance(rc, int) and rc != 0
+            n_plans += 1
+        bp = op.block_plan(feat, cpu)
+        if bp is not None:
+            rc = lib.sgp_spmm_blk_f32(P(bp.uptr), P(bp.ucol), P(bp.usplit), P(bp.wptr), P(bp.nsteps), P(bp.soff),
+                                      P(bp.sw), P(bp.rowmap), bp.n_tiles, bp.waves, bp.max_union, *common)
+            assert isinstance(rc, int) and rc != 0
+            n_plans += 1
+    # reservoir layer: every dispatch branch of the launch logic (split-J, exact deal + tail, even deal, stream)
+    for N, F, R, T in ((207, 3, 64, 5), (20000, 64, 64, 3), (100000, 64, 64, 2), (131072, 8, 32, 2), (40000, 128, 256, 2)):
+        x = torch.zeros(T, N, F); out = torch.zeros(T, N, R)
+        w_ih = torch.zeros(R, F); w_hh = torch.zeros(R, R); b = torch.zeros(R)
+        ws = torch.zeros(max(1, lib.sgp_reservoir_workspace_bytes(F, R) // 4))
+        rc = lib.sgp_reservoir_f32(x.data_ptr(), F, N * F, w_ih.data_ptr(), w_hh.data_ptr(), b.data_ptr(), 0.9, 0,
+                                   out.data_ptr(), R, N * R, None, ws.data_ptr(), T, N, F, R, None)
+        assert isinstance(rc, int) and rc != 0
+        n_plans += 1
+    assert n_plans >= 8, n_plans
+print("asan-ok", n_calls, n_plans)
 ''' % (ROOT, ASAN_LIB)
     env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
     res = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)

@@ -213,6 +213,28 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
 int32_t sgp_spmm_mix_max_union(void);
 int32_t sgp_spmm_mix_max_dense(int32_t halo);
 
+/* Column-blocked hop for graphs without locality (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
+ * sgp_amd/colblock.py).  The columns are cut into n_blocks blocks of consecutive columns whose source
+ * rows fit the L2 of an XCD; n_wg persistent workgroups (16 waves) each own a contiguous range of at
+ * most sgp_spmm_colblock_rows_cap() rows for all time steps and sweep the blocks in the same order, so
+ * every gather of a sweep is served by the L2; partial sums of a step stay in LDS.  Arrays:
+ *   plan[n_entries][2]            {column | (row - wg_row0[wg]) << 23, weight bits}: the edges of a
+ *                                 (workgroup, block) segment row by row, padded with weight-0 entries
+ *                                 to a multiple of 64 * sgp_spmm_colblock_round_pad()
+ *   segptr[n_wg * n_blocks + 1]   first ROUND (64 entries) of segment (wg, block)
+ *   wg_row0[n_wg + 1]             first row of every workgroup
+ * feat must be a multiple of 64 (one launch dimension per 64 features), n_cols < 2^23; no halo source
+ * (a node partition of such a graph uses sgp_spmm_csr_f32).  The sums of a row meet through LDS float
+ * atomics: their order, hence the last bits of a result, may differ between runs. */
+int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int32_t* wg_row0,
+                          int32_t n_wg, int32_t n_blocks,
+                          const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                          float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                          int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                          sgp_stream_t stream);
+int32_t sgp_spmm_colblock_rows_cap(void);
+int32_t sgp_spmm_colblock_round_pad(void);
+
 /* Row-block form of the row-group product (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/rowblock.py).  A workgroup of sgp_spmm_blk_waves() = 8 waves owns a tile of up to 128
  * rows; a wave owns FOUR 4-row groups, one per 16-lane class of v_mfma_f32_4x4x1_16b_f32, and

@@ -138,6 +138,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         }
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
+            if constexpr ((ABL & 512) != 0) { if (p % 3 == 2) continue; }     // (a third fewer staging pieces)
             if (pieces & (1u << p)) {                     // scalar
                 const unsigned dst = piece0 + (unsigned)p * (unsigned)(RPP * 256);
                 if constexpr (HALO) {
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
         // ---- phase B
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(t, 4);
-        asm volatile("s_barrier" ::: "memory");
+        if constexpr ((ABL & 256) == 0) asm volatile("s_barrier" ::: "memory");   // (ablation 256: one barrier per step)
         stamp(t, 5);
         if (dma_first && t + 1 < t_end) dma_segment(x_step + x_inc, h_step + h_inc, piecesA);
         if constexpr (kOneIssuer) { if (wave == NW - 1 && t + 1 < t_end) dma_all(x_step + x_inc, false); }
@@ -446,7 +447,7 @@ int launch_res(const ResArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_res");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132) SGP_ABL(64) SGP_ABL(72)
+    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132) SGP_ABL(64) SGP_ABL(72) SGP_ABL(256) SGP_ABL(512) SGP_ABL(768) SGP_ABL(257)
 #undef SGP_ABL
 #endif
     auto kern = spmm_res<HALO, NW, G, D, PASSES>;

@@ -222,6 +222,25 @@ class ShiftOperator:
             self._plans[key] = plan
         return self._plans[key]
 
+    def colblock_plan(self, feat, device):
+        """Column-blocked plan (``sgp_amd.colblock``, kernel ``sgp_spmm_colblock_f32``) for graphs
+        without locality, or None (feature widths that are not multiples of 64, >= 2^23 columns)."""
+        key = ("colblock", feat, str(device))
+        if key not in self._plans:
+            plan = None
+            if feat % 64 == 0 and self.num_cols < (1 << 23) and self.nnz() > 0:
+                from . import colblock, hip
+                lib = hip.load()
+                plan = colblock.build_colblock_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                                    self.num_nodes, self.num_cols, feat,
+                                                    rows_cap=lib.sgp_spmm_colblock_rows_cap(),
+                                                    round_pad=lib.sgp_spmm_colblock_round_pad(),
+                                                    l2_bytes=float(os.environ.get("SGP_COLBLOCK_L2_MB", "2.5")) * 2 ** 20)
+                if plan is not None:
+                    plan = plan.to(device)
+            self._plans[key] = plan
+        return self._plans[key]
+
     def mix_plan(self, feat, device, strict=True):
         """Mixed dense / sparse plan (``sgp_amd.mixplan``, kernel ``sgp_spmm_mix_f32``) on the tiles and
         row groups of the 64-row plan, or None: needs feature widths that are multiples of 64, a
@@ -265,7 +284,7 @@ class ShiftOperator:
                              f"{self.num_cols} columns, {y.shape[1]} result rows for {self.num_nodes}")
         if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
             raise ValueError("halo batch / feature size differs from x")
-        plan = None if force == "csr" else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
+        plan = None if force in ("csr", "colblock") else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,
         # far * xhrs, n_rows * yrs < 2^30); beyond that -- e.g. a [rows, T, D] halo receive buffer of a
         # long time chunk, whose row stride is T * D -- the generic CSR kernel (64-bit addressing) serves
@@ -329,6 +348,21 @@ class ShiftOperator:
                 raise NotImplementedError("a reordered plan serves the row-group kernels only")
             plan = None                       # generic CSR kernel
             self.last_kernel = "spmm_csr_rows"
+        # no tile plan (no locality to stage): when a time step's source rows exceed an L2 and the rows
+        # are not nearly empty, the column-blocked kernel keeps the gathers inside the L2 (random 100-column
+        # rows at N = 100k: 3x the generic kernel); small or very sparse operators stay with CSR
+        if force == "colblock" or (force is None and plan is None and halo is None and fits32
+                                   and x.shape[2] % 64 == 0 and x.shape[0] >= 4
+                                   and self.num_cols * x.shape[2] * 4 > 3 * 2 ** 20
+                                   and self.nnz() >= 16 * self.num_nodes
+                                   and os.environ.get("SGP_SPMM_COLBLOCK", "1") != "0"):
+            cplan = self.colblock_plan(x.shape[2], x.device) if halo is None else None
+            if cplan is not None:
+                self.last_kernel = "spmm_colblock"
+                hip.spmm_colblock(cplan, x, y)
+                return y
+            if force == "colblock":
+                raise NotImplementedError("no column-blocked plan for this operator / feature width / halo")
         if use_res:
             hip.spmm_res(plan, x, y, halo, self.num_nodes)
         elif use_pipe:

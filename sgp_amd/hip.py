@@ -133,6 +133,10 @@ SIGNATURES = {
     "sgp_grouped_linear_transpose_f32": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
     "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                     c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+                                             c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_spmm_colblock_rows_cap": (c_i32, []),
+    "sgp_spmm_colblock_round_pad": (c_i32, []),
     "sgp_event_create": (ctypes.c_int, [ctypes.POINTER(c_p)]),
     "sgp_event_destroy": (ctypes.c_int, [c_p]),
     "sgp_event_record": (ctypes.c_int, [c_p, c_p]),
@@ -385,6 +389,19 @@ def spmm_blk(plan, x, y, halo=None, n_own=None):
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_blk_f32")
+
+
+@_on_device
+def spmm_colblock(plan, x, y):
+    """Column-blocked hop for graphs without locality (plan: sgp_amd.colblock.ColBlockPlan on the device
+    of ``x``)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    _check(lib.sgp_spmm_colblock_f32(
+        plan.entries.data_ptr(), plan.segptr.data_ptr(), plan.wg_row0.data_ptr(), plan.n_wg, plan.n_blocks,
+        xp, xrs, xbs, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], _stream(x)),
+        "sgp_spmm_colblock_f32")
 
 
 def tiled_limits(feat):

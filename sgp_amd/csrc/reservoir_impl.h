@@ -504,13 +504,25 @@ int launch_stream(ResArgs a, hipStream_t s) {
 // for the SAME 16 nodes, then exchange the new state through a double-buffered LDS slab (the
 // C-layout tile of a wave is written as-is: it is already the B-operand layout every wave
 // needs), one barrier per step.
-constexpr int kSplitjRing = 8;       // input-row ring of the split-J kernel (time steps)
+// Input-row ring of the split-J kernel (time steps): 8 deep when three workgroups fit a CU's LDS anyway
+// (narrow inputs), else the deepest of 4 / 3 / 2 that lets three fit -- a mid-size graph (513-768 node
+// tiles, e.g. N = 10 000) then runs as ONE round of split-J workgroups, 3 per CU, instead of one
+// single-tile wave per SIMD with a 128-MFMA chain per step (F = R = 64: ring 3, 54 KB per workgroup).
+constexpr long long splitj_fixed_bytes(int JT, int NKX) {
+    return ((long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4;
+}
+constexpr int splitj_ring(int JT, int NKX) {
+    const int opts[] = {8, 4, 3, 2};
+    for (int o : opts)
+        if (3 * (splitj_fixed_bytes(JT, NKX) + (long long)o * NKX * 64 * 4) <= 160 * 1024) return o;
+    return 8;
+}
 
 template <int JT, int NKX, bool OVEC>
 __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
     static_assert(JT % 4 == 0, "split-J needs at least one j-tile per wave");
     constexpr int JW = JT / 4;                           // j-tiles per wave
-    constexpr int PFD = kSplitjRing;
+    constexpr int PFD = splitj_ring(JT, NKX);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     {
         const int total4 = (int)(packed_floats(JT, NKX) / 4);
@@ -714,7 +726,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
 
 template <int JT, int NKX>
 constexpr long long splitj_lds_bytes() {
-    return packed_floats(JT, NKX) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4 + (long long)kSplitjRing * NKX * 64 * 4;
+    return splitj_fixed_bytes(JT, NKX) + (long long)splitj_ring(JT, NKX) * NKX * 64 * 4;
 }
 
 template <int JT, int NKX, int NT>
@@ -785,8 +797,9 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
     constexpr bool kSplitj = JT % 4 == 0 && splitj_lds_bytes<JT, NKX>() <= kLdsLimit;
     if constexpr (kSplitj) {
-        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 512);
-        if (n_tiles <= splitj_max)                  // a few workgroups per CU: latency-bound regime
+        // up to 2 (3 where three fit a CU's LDS) workgroups per CU, all resident at once
+        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 3 * splitj_lds_bytes<JT, NKX>() <= kLdsLimit ? 768 : 512);
+        if (n_tiles <= splitj_max)
             return launch_splitj<JT, NKX>(a, n_tiles, s);
     }
     if constexpr (JT <= 4 && kSplitj) {

@@ -7,7 +7,11 @@ The reference is single-process; the encoder nevertheless shards naturally:
 * hop k: rank g computes its rows of ``A . X`` and needs ``X[:, c, :]`` for every column its
   rows reference -- owned columns are local, the rest ("halo") are fetched from their owners
   with ONE ``all_to_all_single`` per hop over RCCL/xGMI (point-to-point links: every peer's
-  rows travel their own link, nothing is relayed);
+  rows travel their own link, nothing is relayed).  When the halo is nearly everything (a graph
+  without locality that no renumbering rescues: the ranks together need more than half of all
+  remote rows) the packing buys nothing and costs a gather kernel per hop: the exchange is then ONE
+  ``all_gather`` of every rank's full shard (SURVEY.md 8e's general case) and the local operator
+  addresses the gathered buffer directly;
 * ``global_attr``: ``all_reduce(sum)`` of the ``[T, D_h]`` partial column sums.
 
 One process per GPU; ``torch.distributed`` supplies the process group (``nccl`` == RCCL on
@@ -71,6 +75,10 @@ class LocalBlock:
     recv_counts: List[int]            # halo rows owned by each peer (contiguous in halo order)
     send_index: torch.Tensor          # int32 [sum(send_counts)] LOCAL row ids, peer-major
     send_counts: List[int]            # rows each peer needs from me
+    gather_rows: int = 0              # > 0: all_gather exchange; every rank contributes this many rows
+    #                                   (its shard padded to the largest one) and ``op``'s halo columns
+    #                                   index the gathered buffer: column n_own + p * gather_rows + i is
+    #                                   row bounds[p] + i
 
     @property
     def n_own(self):
@@ -78,6 +86,8 @@ class LocalBlock:
 
     @property
     def n_halo(self):
+        if self.gather_rows:
+            return self.gather_rows * len(self.recv_counts)
         return int(self.halo_global.numel())
 
 
@@ -88,32 +98,45 @@ def _halo_of(op, lo, hi):
     return torch.unique(outside, sorted=True), cols
 
 
-def split_operator(op: ShiftOperator, bounds, rank) -> LocalBlock:
+def split_operator(op: ShiftOperator, bounds, rank, exchange="auto") -> LocalBlock:
     """Local block of ``rank`` plus the halo bookkeeping, computed from the full operator
-    (every rank holds the whole graph: it is tiny next to the node features)."""
+    (every rank holds the whole graph: it is tiny next to the node features).
+    ``exchange``: "packed" = all_to_all of the rows peers reference, "gather" = all_gather of full
+    shards, "auto" = gather when the ranks together reference more than half of all remote rows
+    (every rank evaluates the same global figure, so all take the same branch)."""
     world = len(bounds) - 1
     lo, hi = bounds[rank], bounds[rank + 1]
     halo, cols = _halo_of(op, lo, hi)
     n_own = hi - lo
     own = (cols >= lo) & (cols < hi)
-    local = torch.where(own, cols - lo, n_own + torch.searchsorted(halo, cols))
     rp = op.rowptr.long()
     rowptr = rp[lo:hi + 1] - rp[lo]
     vals = op.val[rp[lo]:rp[hi]]
-    block = ShiftOperator(rowptr, local, vals, n_own, num_cols=n_own + int(halo.numel()))
     b = torch.tensor(bounds)
     owner = torch.bucketize(halo, b[1:], right=True)                # rank owning each halo column
     recv_counts = torch.bincount(owner, minlength=world).tolist()
     send_idx, send_counts = [], []
+    halo_total = int(halo.numel())
     for p in range(world):                                          # what does p need from me?
         if p == rank:
             send_counts.append(0)
             continue
         ph, _ = _halo_of(op, bounds[p], bounds[p + 1])
+        halo_total += int(ph.numel())
         mine = ph[(ph >= lo) & (ph < hi)] - lo
         send_idx.append(mine)
         send_counts.append(int(mine.numel()))
     send_index = (torch.cat(send_idx) if send_idx else torch.zeros(0, dtype=torch.long)).int()
+    n = int(bounds[-1])
+    remote_total = sum(n - (bounds[p + 1] - bounds[p]) for p in range(world))
+    if exchange == "gather" or (exchange == "auto" and world > 1 and 2 * halo_total > remote_total):
+        g_rows = max(bounds[p + 1] - bounds[p] for p in range(world))
+        col_owner = torch.bucketize(cols, b[1:], right=True)
+        local = torch.where(own, cols - lo, n_own + col_owner * g_rows + (cols - b[col_owner]))
+        block = ShiftOperator(rowptr, local, vals, n_own, num_cols=n_own + world * g_rows)
+        return LocalBlock(block, lo, hi, halo, recv_counts, send_index, send_counts, gather_rows=int(g_rows))
+    local = torch.where(own, cols - lo, n_own + torch.searchsorted(halo, cols))
+    block = ShiftOperator(rowptr, local, vals, n_own, num_cols=n_own + int(halo.numel()))
     return LocalBlock(block, lo, hi, halo, recv_counts, send_index, send_counts)
 
 
@@ -148,18 +171,35 @@ class HaloExchange:
         self._idx = None
 
     def _buffers(self, T, D, device):
-        shape_s = (sum(self.block.send_counts), T, D)
+        g = self.block.gather_rows
+        shape_s = (g if g else sum(self.block.send_counts), T, D)
         shape_r = (self.block.n_halo, T, D)
         if self._send is None or self._send.shape != shape_s or self._send.device != device:
-            self._send = torch.empty(shape_s, dtype=torch.float32, device=device)
+            # (gather form: the rows past a short shard are never referenced, but they travel: keep them finite)
+            self._send = (torch.zeros if g else torch.empty)(shape_s, dtype=torch.float32, device=device)
             self._recv = torch.empty(shape_r, dtype=torch.float32, device=device)
-            self._idx = self.block.send_index.to(device)
+            self._idx = (torch.arange(self.block.n_own, dtype=torch.int32) if g else self.block.send_index).to(device)
         return self._send, self._recv
+
+    def _all_gather(self, x, send, recv):
+        """General case: every rank's full shard (padded to the largest) to every rank."""
+        if self.block.n_own:
+            self.ops.gather_nodes(x, self._idx, send.permute(1, 0, 2)[:, :self.block.n_own])
+        world = len(self.block.recv_counts)
+        if send.is_cuda and dist.get_backend(self.group) == "gloo":      # shared-GPU test rigs only
+            parts = [torch.empty(send.shape, dtype=send.dtype) for _ in range(world)]
+            dist.all_gather(parts, send.cpu(), group=self.group)
+            recv.copy_(torch.cat(parts, 0))
+        else:
+            dist.all_gather(list(recv.chunk(world, 0)), send, group=self.group)
+        return recv.permute(1, 0, 2)
 
     def __call__(self, x):
         """x[T, n_own, D] (strided view) -> halo[T, n_halo, D] view of the receive buffer."""
         T, _, D = x.shape
         send, recv = self._buffers(T, D, x.device)
+        if self.block.gather_rows:
+            return self._all_gather(x, send, recv)
         if send.shape[0]:
             self.ops.gather_nodes(x, self._idx, send.permute(1, 0, 2))
         if send.is_cuda and dist.get_backend(self.group) == "gloo":
@@ -346,7 +386,8 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
 
 def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
                              rank=None, world_size=None, group=None, ops=HipOps,
-                             balance="nnz", n_chunks=4, force_collectives=False, locality="auto"):
+                             balance="nnz", n_chunks=4, force_collectives=False, locality="auto",
+                             exchange="auto"):
     """Split the forward (and backward) global operators for this rank.
 
     Returns ``(spatial, bounds)``; ``spatial.node_order`` is None when rank r owns the global
@@ -357,7 +398,9 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
     more than half as many halo rows as it owns (a k-NN graph of stations in file order:
     near-full exchange) and the renumbering fetches at least 30 % fewer; "never" keeps the
     numbering; "always" renumbers.
-    ``balance``: "nnz" cuts equal edge counts (equal SpMM work), "rows" equal row counts."""
+    ``balance``: "nnz" cuts equal edge counts (equal SpMM work), "rows" equal row counts.
+    ``exchange``: see ``split_operator`` ("auto": all_gather of full shards instead of the packed
+    all_to_all when the ranks together reference more than half of all remote rows)."""
     rank = dist.get_rank(group) if rank is None else rank
     world_size = dist.get_world_size(group) if world_size is None else world_size
     n = ops_global[0].num_nodes
@@ -384,7 +427,7 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
                     warnings.warn("make_partitioned_spatial: the node numbering has no locality; rank r owns "
                                   "spatial.node_order[bounds[r]:bounds[r+1]], not the contiguous range "
                                   "(pass locality='never' to keep the numbering)", stacklevel=2)
-    blocks = [split_operator(op, bounds, rank) for op in ops_global]
+    blocks = [split_operator(op, bounds, rank, exchange=exchange) for op in ops_global]
     spatial = PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
                                  n_chunks=n_chunks, force_collectives=force_collectives)
     spatial.node_order = node_order

@@ -1063,6 +1063,22 @@ def test_bench_baseline_partitioned_configs_share_one_gpu(tmp_path, workload, gp
         assert seen == one["ids"].numel()
 
 
+def test_bench_gather_exchange_on_a_graph_without_locality(tmp_path):
+    """SURVEY 8e's general case end to end: a random graph partitioned over 3 ranks (sharing this GPU
+    over gloo) needs nearly every remote row, so the partitioner exchanges full shards with one
+    all_gather per hop and the local operators address the gathered buffer; == the single-rank result."""
+    env = dict(os.environ, SGP_BENCH_DUMP=str(tmp_path))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    base = ["--workload", "smallrand", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    _run_bench(base, env)
+    rec = _run_bench(base + ["--gpus", "3"], env)
+    assert rec["n_gpus"] == 3 and rec["multi_gpu"]["exchange"].startswith("all_gather")
+    full = torch.load(tmp_path / "out_w1_r0.pt")
+    parts = torch.cat([torch.load(tmp_path / f"out_w3_r{r}.pt") for r in range(3)], 1)
+    close(parts, full, rtol=1e-5, atol=1e-5)
+
+
 def test_bench_under_an_external_launcher(tmp_path):
     """The launcher form of the contract (torch.distributed.run starts the ranks) still works."""
     import subprocess, sys, json

@@ -69,6 +69,36 @@ def test_split_operator_reassembles(world):
             assert torch.equal(want, sent)
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_split_operator_gather_form_reassembles(world):
+    """A graph without locality: the ranks together reference more than half of all remote rows, so the
+    partitioner picks the all_gather exchange; the local operator's halo columns then address the
+    gathered buffer (rank p's shard, padded to the largest, at p * gather_rows)."""
+    ei, ew = synthetic.random_graph(300, 30, seed=1)
+    op = graph.ShiftOperator.from_edges(ei, ew, 300)
+    bounds = partition.partition_bounds(300, world, op.rowptr.numpy())
+    dense = op.to_dense()
+    for r in range(world):
+        b = partition.split_operator(op, bounds, r)
+        g = b.gather_rows
+        assert g == max(bounds[p + 1] - bounds[p] for p in range(world)) and b.n_halo == world * g
+        d = b.op.to_dense()
+        full = torch.zeros(b.n_own, 300)
+        full[:, b.lo:b.hi] = d[:, :b.n_own]
+        for p in range(world):
+            blk = d[:, b.n_own + p * g:b.n_own + p * g + bounds[p + 1] - bounds[p]]
+            if p == r:
+                assert blk.abs().sum() == 0                  # own rows are read from x, not from the buffer
+            else:
+                full[:, bounds[p]:bounds[p + 1]] = blk
+        assert torch.equal(full, dense[b.lo:b.hi])
+        assert partition.split_operator(op, bounds, r, exchange="packed").gather_rows == 0
+    # a graph with locality keeps the packed exchange
+    ei, ew, _ = synthetic.knn_graph(400, 9, seed=2)
+    knn = graph.ShiftOperator.from_edges(ei, ew, 400)
+    assert partition.split_operator(knn, partition.partition_bounds(400, world), 0).gather_rows == 0
+
+
 def _worker(rank, world, port, cfg, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -79,12 +109,19 @@ def _worker(rank, world, port, cfg, ret):
         ei, ew, _ = synthetic.knn_graph(n, 7, seed=4)
         if cfg.get("scramble"):                       # node numbering without locality
             ei = torch.randperm(n, generator=torch.Generator().manual_seed(3))[ei]
+        if cfg.get("random"):                         # no locality at all: every rank needs nearly every row
+            ei, ew = synthetic.random_graph(n, cfg["random"], seed=6)
         ops = spatial_operators(ei, ew, n, bidirectional=cfg["bidir"])
         x = torch.randn(t, n, d)
         enc, bounds = partition.make_partitioned_spatial(ops, k, cfg["glob"], ops=TorchOps,
-                                                         balance=cfg.get("balance", "nnz"))
+                                                         balance=cfg.get("balance", "nnz"),
+                                                         locality=cfg.get("locality", "auto"),
+                                                         exchange=cfg.get("exchange", "auto"))
+        if "gather" in cfg:                           # which exchange the partitioner chose
+            assert all((b.gather_rows > 0) == cfg["gather"] for b in enc.blocks)
         lo, hi = bounds[rank], bounds[rank + 1]
-        assert (enc.node_order is not None) == bool(cfg.get("scramble"))
+        if "random" not in cfg:
+            assert (enc.node_order is not None) == bool(cfg.get("scramble"))
         rows = torch.arange(lo, hi) if enc.node_order is None else enc.node_order[lo:hi]
         out = torch.zeros(t, hi - lo, enc.num_blocks() * d)
         out[:, :, :d] = x[:, rows]
@@ -100,9 +137,14 @@ def _worker(rank, world, port, cfg, ret):
 
 @pytest.mark.parametrize("cfg", [dict(n=150, k=3, bidir=True, glob=True),
                                  dict(n=97, k=2, bidir=False, glob=False, balance="rows"),
-                                 dict(n=900, k=2, bidir=True, glob=True, scramble=True)])
+                                 dict(n=900, k=2, bidir=True, glob=True, scramble=True),
+                                 # SURVEY 8e's general case: halo ~ everything -> all_gather of full shards
+                                 dict(n=301, k=2, bidir=True, glob=True, random=40, locality="never", gather=True),
+                                 dict(n=150, k=2, bidir=False, glob=False, exchange="gather", gather=True),
+                                 dict(n=301, k=2, bidir=False, glob=True, random=40, locality="never", gather=True,
+                                      world=3)])
 def test_two_rank_gloo_matches_single_process(cfg):
-    world = 2
+    world = cfg.get("world", 2)
     port = 29500 + (os.getpid() % 2000)
     mgr = mp.Manager()
     ret = mgr.dict()

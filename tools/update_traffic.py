@@ -1,0 +1,48 @@
+"""profiles/traffic.json from the committed rocprofv3 counter summaries: per (workload, kernel) the fabric
+bytes of one hop launch = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction,
+MI355X_MICROARCH.md HBM section).  python tools/update_traffic.py r3 target:spmm_mix c3:spmm_mix ..."""
+import json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def counters(path, kernel):
+    out, cur = {}, None
+    for line in open(path):
+        m = re.match(r"\s+kernel: (.*)", line)
+        if m:
+            cur = m.group(1)
+            continue
+        m = re.match(r"\s+(FETCH_SIZE|WRITE_SIZE)\s+total \S+\s+per-dispatch (\S+)", line)
+        if m and cur and kernel in cur:
+            out[m.group(1)] = float(m.group(2))
+    return out
+
+
+def main():
+    rnd = sys.argv[1]
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    table = json.load(open(path))
+    for key in sys.argv[2:]:
+        wl, kernel = key.split(":")
+        summ = os.path.join("profiles", rnd, f"{wl}_summary.txt")
+        c = counters(os.path.join(ROOT, summ), kernel)
+        w = bench.WORKLOADS[wl]
+        ei, ew = bench.build_graph(w)
+        d_h = w["R"] * w["L"]
+        t = min(w["T"], w.get("t_chunk", w["T"]))
+        alg = bench.hop_bytes(w["N"], t, d_h, int(ei.shape[1]))
+        b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000.0
+        table[key] = {"bytes_per_launch": b, "fetch_size_kb_raw": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
+                      "algorithmic_bytes": alg, "ratio_to_algorithmic": round(b / alg, 3),
+                      "source": f"{summ} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
+                                f"--workload {wl}`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB, gfx950 FETCH_SIZE correction "
+                                f"of MI355X_MICROARCH.md)"}
+        print(key, table[key]["bytes_per_launch"], table[key]["ratio_to_algorithmic"])
+    json.dump(table, open(path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

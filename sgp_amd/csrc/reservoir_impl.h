@@ -505,9 +505,9 @@ int launch_stream(ResArgs a, hipStream_t s) {
 // C-layout tile of a wave is written as-is: it is already the B-operand layout every wave
 // needs), one barrier per step.
 // Input-row ring of the split-J kernel (time steps): 8 deep when three workgroups fit a CU's LDS anyway
-// (narrow inputs), else the deepest of 4 / 3 / 2 that lets three fit -- a mid-size graph (513-768 node
-// tiles, e.g. N = 10 000) then runs as ONE round of split-J workgroups, 3 per CU, instead of one
-// single-tile wave per SIMD with a 128-MFMA chain per step (F = R = 64: ring 3, 54 KB per workgroup).
+// (narrow inputs), else the deepest of 4 / 3 / 2 that lets three fit (F = R = 64: ring 3, 54 KB per
+// workgroup; the split-J tail of a large problem shares its CU's LDS with nothing and lost nothing to
+// the shorter ring: N = 100k 4.48 -> 4.30 ms per 256 steps).
 constexpr long long splitj_fixed_bytes(int JT, int NKX) {
     return ((long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256) * 4 + 2ll * JT * 64 * 16 + 2 * 64 * 4;
 }
@@ -797,8 +797,10 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
     const int n_tiles = (a.N + 15) / 16;
     constexpr bool kSplitj = JT % 4 == 0 && splitj_lds_bytes<JT, NKX>() <= kLdsLimit;
     if constexpr (kSplitj) {
-        // up to 2 (3 where three fit a CU's LDS) workgroups per CU, all resident at once
-        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 3 * splitj_lds_bytes<JT, NKX>() <= kLdsLimit ? 768 : 512);
+        // up to 2 workgroups per CU.  (Three per CU -- 513-768 tiles in one round, which the 3-deep ring
+        // makes possible at F = R = 64 -- measured slower than one single-tile wave per SIMD: N = 10 000,
+        // 1.53 vs 1.37 ms per 512 steps; SGP_RES_SPLITJ_MAX=768 selects it.)
+        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 512);
         if (n_tiles <= splitj_max)
             return launch_splitj<JT, NKX>(a, n_tiles, s);
     }

@@ -1,6 +1,8 @@
 """profiles/traffic.json from the committed rocprofv3 counter summaries: per (workload, kernel) the fabric
 bytes of one hop launch = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction,
-MI355X_MICROARCH.md HBM section).  python tools/update_traffic.py r3 target:spmm_mix c3:spmm_mix ..."""
+MI355X_MICROARCH.md HBM section).  python tools/update_traffic.py r3 target:spmm_mix c3:spmm_mix c2:spmm_tiled:8 ...
+(a third field = the number of time pieces a pass cuts a hop into: the counters are per dispatch, the table
+is per hop over the whole time axis, which is what bench.py divides by its own piece count)"""
 import json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -26,7 +28,9 @@ def main():
     path = os.path.join(ROOT, "profiles", "traffic.json")
     table = json.load(open(path))
     for key in sys.argv[2:]:
-        wl, kernel = key.split(":")
+        parts = key.split(":")
+        wl, kernel, pieces = parts[0], parts[1], int(parts[2]) if len(parts) > 2 else 1
+        key = f"{wl}:{kernel}"
         summ = os.path.join("profiles", rnd, f"{wl}_summary.txt")
         c = counters(os.path.join(ROOT, summ), kernel)
         w = bench.WORKLOADS[wl]
@@ -34,6 +38,7 @@ def main():
         d_h = w["R"] * w["L"]
         t = min(w["T"], w.get("t_chunk", w["T"]))
         alg = bench.hop_bytes(w["N"], t, d_h, int(ei.shape[1]))
+        c = {k: v * pieces for k, v in c.items()}
         b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000.0
         table[key] = {"bytes_per_launch": b, "fetch_size_kb_raw": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
                       "algorithmic_bytes": alg, "ratio_to_algorithmic": round(b / alg, 3),

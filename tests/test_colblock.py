@@ -125,3 +125,42 @@ def test_colblock_ragged_rows_strided_slots_and_auto_choice():
     assert small.last_kernel != "spmm_colblock"
     with pytest.raises(NotImplementedError):
         small.propagate(torch.randn(4, 500, 48, device="cuda"), torch.empty(4, 500, 48, device="cuda"), force="colblock")
+
+
+@pytest.mark.gpu
+def test_colblock_nan_in_one_source_row_stays_in_the_rows_that_reference_it():
+    """Padding entries read a real column with weight 0; 0 * NaN must not leak into a neighbouring
+    row's sum (they end a run of a spare LDS row).  Also: more workgroups than CUs (no rendezvous) and
+    two feature tiles."""
+    torch.manual_seed(8)
+    n, t, feat = 12000, 3, 128
+    ei, ew = synthetic.random_graph(n, 40, seed=11)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    plan = op.colblock_plan(feat, torch.device("cuda"))
+    assert plan.n_blocks >= 2
+    bad = [0, plan.cols_per_block, n - 1]                       # first column of two blocks (what padding reads) and the last one
+    x = torch.randn(t, n, feat)
+    x[:, bad] = float("nan")
+    y = torch.empty(t, n, feat, device="cuda")
+    op.propagate(x.cuda(), y, force="colblock")
+    rowptr, col, _ = op.csr()
+    hit = torch.isin(col, torch.tensor(bad))
+    touched = torch.zeros(n, dtype=torch.bool)
+    touched[torch.repeat_interleave(torch.arange(n), rowptr[1:] - rowptr[:-1])[hit]] = True
+    got = torch.isnan(y).any(2).any(0).cpu()
+    assert torch.equal(got, touched), (int(got.sum()), int(touched.sum()))
+    x0 = torch.nan_to_num(x, nan=0.0)
+    y0 = torch.empty_like(y)
+    op.propagate(x0.cuda(), y0, force="colblock")
+    ok = ~touched
+    assert torch.allclose(y[:, ok.cuda()].cpu(), y0[:, ok.cuda()].cpu(), rtol=0, atol=0)
+    # a plan with more workgroups than the chip has CUs: the per-step rendezvous is skipped, results unchanged
+    from sgp_amd import colblock, hip
+    rowptr, col, val = op.csr()
+    many = colblock.build_colblock_plan(rowptr.numpy(), col.numpy(), val.numpy(), n, n, feat, n_wg=400,
+                                        rows_cap=hip.load().sgp_spmm_colblock_rows_cap(),
+                                        round_pad=hip.load().sgp_spmm_colblock_round_pad()).to(torch.device("cuda"))
+    assert many.n_wg >= 300
+    y1 = torch.empty_like(y0)
+    hip.spmm_colblock(many, x0.cuda(), y1)
+    assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-5)

@@ -150,6 +150,8 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
         if (a.mode & 16) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
+            if constexpr ((ABL & 512) != 0) { if (p % 3 == 2) continue; }     // (ablation: a third fewer staging pieces)
+            if constexpr ((ABL & 1024) != 0) { if (p % 2 == 1) continue; }    // (ablation: half the staging pieces)
             if (pieces & (1u << p)) {                     // scalar
                 const unsigned dst = piece0 + (unsigned)p * (unsigned)(RPP * 256);
                 if constexpr (HALO) {
@@ -597,7 +599,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_mix");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129)
+    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129) SGP_ABL(512) SGP_ABL(1024)
 #undef SGP_ABL
 #endif
     auto kern = spmm_mix<HALO, SH, DH, D, DD, ILV>;

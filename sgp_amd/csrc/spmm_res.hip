@@ -139,6 +139,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_res(ResArgs a) {
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
             if constexpr ((ABL & 512) != 0) { if (p % 3 == 2) continue; }     // (a third fewer staging pieces)
+            if constexpr ((ABL & 1024) != 0) { if (p % 2 == 1) continue; }    // (half the staging pieces)
             if (pieces & (1u << p)) {                     // scalar
                 const unsigned dst = piece0 + (unsigned)p * (unsigned)(RPP * 256);
                 if constexpr (HALO) {
@@ -447,7 +448,7 @@ int launch_res(const ResArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_res");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132) SGP_ABL(64) SGP_ABL(72) SGP_ABL(256) SGP_ABL(512) SGP_ABL(768) SGP_ABL(257)
+    SGP_ABL(1) SGP_ABL(4) SGP_ABL(16) SGP_ABL(32) SGP_ABL(128) SGP_ABL(129) SGP_ABL(132) SGP_ABL(64) SGP_ABL(72) SGP_ABL(256) SGP_ABL(512) SGP_ABL(768) SGP_ABL(257) SGP_ABL(1024)
 #undef SGP_ABL
 #endif
     auto kern = spmm_res<HALO, NW, G, D, PASSES>;

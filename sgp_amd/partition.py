@@ -98,12 +98,13 @@ def _halo_of(op, lo, hi):
     return torch.unique(outside, sorted=True), cols
 
 
-def split_operator(op: ShiftOperator, bounds, rank, exchange="auto") -> LocalBlock:
+def split_operator(op: ShiftOperator, bounds, rank, exchange="packed") -> LocalBlock:
     """Local block of ``rank`` plus the halo bookkeeping, computed from the full operator
     (every rank holds the whole graph: it is tiny next to the node features).
-    ``exchange``: "packed" = all_to_all of the rows peers reference, "gather" = all_gather of full
-    shards, "auto" = gather when the ranks together reference more than half of all remote rows
-    (every rank evaluates the same global figure, so all take the same branch)."""
+    ``exchange``: "packed" (default here) = all_to_all of the rows peers reference, "gather" =
+    all_gather of full shards, "auto" (what ``make_partitioned_spatial`` passes) = gather when the
+    ranks together reference more than half of all remote rows (every rank evaluates the same global
+    figure, so all take the same branch)."""
     world = len(bounds) - 1
     lo, hi = bounds[rank], bounds[rank + 1]
     halo, cols = _halo_of(op, lo, hi)

@@ -360,6 +360,27 @@ def test_reservoir_wide_streamed_weights(act, f, r):
     close(state[0], out[-1], rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("n,f,r", [(20007, 5, 64), (40000, 64, 64), (16384 + 16 * 600, 3, 32), (131072, 4, 16)])
+def test_reservoir_exact_deal_and_split_j_tail(n, f, r):
+    """Large N: 1024 SIMDs x per tiles in the main kernel (one 16-wave workgroup per CU) + the tiles that
+    are left in the split-J kernel (launch_nt, reservoir_impl.h) -- against the oracle, ragged last
+    tile included, and the state carried across two calls (main part and tail share h_state)."""
+    torch.manual_seed(n % 97)
+    t = 5
+    res = sgp_amd.Reservoir(f, r)
+    x = torch.randn(t, n, f)
+    out = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x.cuda(), out)
+    ref = O.reservoir_forward(x, layers_of(res))
+    close(out, ref)
+    state = torch.zeros(1, n, r, device="cuda")
+    out2 = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x[:2].cuda(), out2[:2], state)
+    res.encode_into(x[2:].cuda(), out2[2:], state)
+    assert torch.equal(out2, out)
+    assert torch.equal(state[0], out[-1])
+
+
 def test_reservoir_state_carry_equals_one_shot():
     torch.manual_seed(1)
     res = sgp_amd.Reservoir(4, 32, num_layers=2, alpha_decay=True)

@@ -79,7 +79,7 @@ def test_split_operator_gather_form_reassembles(world):
     bounds = partition.partition_bounds(300, world, op.rowptr.numpy())
     dense = op.to_dense()
     for r in range(world):
-        b = partition.split_operator(op, bounds, r)
+        b = partition.split_operator(op, bounds, r, exchange="auto")
         g = b.gather_rows
         assert g == max(bounds[p + 1] - bounds[p] for p in range(world)) and b.n_halo == world * g
         d = b.op.to_dense()
@@ -96,7 +96,7 @@ def test_split_operator_gather_form_reassembles(world):
     # a graph with locality keeps the packed exchange
     ei, ew, _ = synthetic.knn_graph(400, 9, seed=2)
     knn = graph.ShiftOperator.from_edges(ei, ew, 400)
-    assert partition.split_operator(knn, partition.partition_bounds(400, world), 0).gather_rows == 0
+    assert partition.split_operator(knn, partition.partition_bounds(400, world), 0, exchange="auto").gather_rows == 0
 
 
 def _worker(rank, world, port, cfg, ret):

@@ -599,7 +599,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_mix");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129) SGP_ABL(512) SGP_ABL(1024)
+    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129) SGP_ABL(512) SGP_ABL(1024) SGP_ABL(640) SGP_ABL(1152)
 #undef SGP_ABL
 #endif
     auto kern = spmm_mix<HALO, SH, DH, D, DD, ILV>;

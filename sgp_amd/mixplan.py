@@ -78,10 +78,12 @@ def _deal_classes(sp):
     return cls
 
 
-def build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=4, dh=10):
+def build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=4, dh=10, pad_dense=False):
     """Mixed plan for tiles ``trow`` whose rows already sit in group order (``slot_of_row``: position
     of every row inside its tile; rows 4 g .. 4 g + 3 form group g).  Returns a dict of numpy arrays
-    (see the module docstring) plus statistics."""
+    (see the module docstring) plus statistics.  ``pad_dense`` (the all-dense kernel, ``sgp_spmm_dense_f32``,
+    with ``thr=1``): EVERY candidate column stays dense and a (block, phase) list is padded to whole
+    instructions with weight-0 columns (staged row 0) instead of demoting what does not fill one."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
     n_tiles = len(trow) - 1
@@ -115,7 +117,7 @@ def build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=4, dh=10):
     cand = cnt2 >= thr
     n_bp = n_tiles * BLOCKS_PER_TILE * 2
     n_cand = np.bincount(bp2[cand], minlength=n_bp)
-    n_keep = np.minimum(n_cand // 4, dh) * 4
+    n_keep = n_cand.copy() if pad_dense else np.minimum(n_cand // 4, dh) * 4
     order = np.lexsort((lc2, -cnt2, bp2, ~cand))                          # candidates first, by (bp, most shared, column)
     order = order[:int(cand.sum())]
     start = np.zeros(n_bp + 1, dtype=np.int64)
@@ -151,7 +153,7 @@ def build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=4, dh=10):
     d_ids = np.flatnonzero(dense2)
     d_ids = d_ids[np.lexsort((stage2[d_ids], bp2[d_ids]))]                # by (block, phase), then staged slot
     # (the block index inside a tile must follow the NEW slots: block b of the tile = slots 16 b ..)
-    n_inst = n_keep // 4
+    n_inst = (n_keep + 3) // 4
     dptr = np.zeros(n_bp + 1, dtype=np.int64)
     dptr[1:] = np.cumsum(n_inst)
     dstart = np.zeros(n_bp + 1, dtype=np.int64)
@@ -243,7 +245,7 @@ class MixPlan:
         return MixPlan(d, self.n_tiles, self.n_rows, self.reordered)
 
 
-def build_mix_plan(rowptr, col, val, n_rows, base, thr=4, dh=10, order=None):
+def build_mix_plan(rowptr, col, val, n_rows, base, thr=4, dh=10, order=None, pad_dense=False):
     """Mixed plan on the tiles and row groups of ``base`` (a ``graph.TilePlan`` with a two-phase
     stream).  ``order`` (new id k = old id ``order[k]``): ``base`` was built on the renumbered
     operator (``graph.build_reordered_plan``); the plan then addresses ORIGINAL ids through ``ucol``
@@ -270,7 +272,7 @@ def build_mix_plan(rowptr, col, val, n_rows, base, thr=4, dh=10, order=None):
     slot_of_row = np.zeros(n_rows, dtype=np.int64)
     ok = np.flatnonzero(rowmap >= 0)
     slot_of_row[rowmap[ok]] = ok % TILE_SLOTS
-    arrays = build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=thr, dh=dh)
+    arrays = build_mix_stream(rowptr, col, val, trow, slot_of_row, thr=thr, dh=dh, pad_dense=pad_dense)
     if order is not None:
         o32 = order.astype(np.int32)
         arrays["ucol"] = o32[arrays["ucol"].astype(np.int64)]

@@ -145,8 +145,15 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     const char* x_step = reinterpret_cast<const char*>(a.src.x + (long long)t_begin * a.src.xbs);
     const char* h_step = reinterpret_cast<const char*>(a.src.xh + (long long)t_begin * a.src.xhbs);
     const long long x_inc = a.src.xbs * 4, h_inc = a.src.xhbs * 4;
+    const char* const x_step0 = x_step;
+    const char* const h_step0 = h_step;
     auto dma_segment = [&](const char* xt, const char* ht, unsigned pieces) {
         if constexpr (ABL & 1) return;
+        if constexpr ((ABL & 2048) != 0) { xt = x_step0; ht = h_step0; }   // (ablation: every staging read hits the L2)
+        if constexpr ((ABL & 4096) != 0) {                                    // (ablation: every row set staged for 2 steps in a row: half hit)
+            const long long kk = (xt - x_step0) / x_inc / 2 * 2;
+            xt = x_step0 + kk * x_inc; ht = h_step0 + kk * h_inc;
+        }
         if (a.mode & 16) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int p = 0; p < PASSES; ++p) {
@@ -599,7 +606,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(k4, grid, dim3(NW * 64), lds_bytes, s, a);                              \
         return sgp::check_launch("spmm_mix");                                                      \
     }
-    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129) SGP_ABL(512) SGP_ABL(1024) SGP_ABL(640) SGP_ABL(1152)
+    SGP_ABL(1) SGP_ABL(2) SGP_ABL(4) SGP_ABL(3) SGP_ABL(5) SGP_ABL(128) SGP_ABL(129) SGP_ABL(512) SGP_ABL(1024) SGP_ABL(640) SGP_ABL(1152) SGP_ABL(2048) SGP_ABL(4096)
 #undef SGP_ABL
 #endif
     auto kern = spmm_mix<HALO, SH, DH, D, DD, ILV>;

@@ -213,6 +213,36 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
 int32_t sgp_spmm_mix_max_union(void);
 int32_t sgp_spmm_mix_max_dense(int32_t halo);
 
+/* out[0] = max |X| over a strided [batch, n_rows, feat] view (device scalar; non-finite inputs give a
+ * non-finite value).  Serves callers of sgp_spmm_split_f32 that have no analytic bound on their operand
+ * (`sgp_spatial_embedding` on arbitrary [B, N, F] batches, lib/nn/models/sgp_model.py:169-181; relu
+ * reservoirs).  Widths that are multiples of 4 need 16-byte aligned rows. */
+int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                    int32_t n_rows, int32_t batch, int32_t feat, float* out, sgp_stream_t stream);
+
+/* Split-fp16 hop (lib/sgp_preprocessing.py:200-203, `x = adj @ x` per hop; plan: sgp_amd/splitplan.py;
+ * kernel: csrc/spmm_split.hip).  Every operand value is carried as two fp16 pieces of its scaled self
+ * (v * scale = hi + lo, 22 significant bits) and every product as hi*hi + hi*lo + lo*hi accumulated in fp32
+ * by v_mfma_f32_16x16x32_f16: results agree with an fp32 evaluation to ~1e-7 of the input scale (measured
+ * against fp64: closer than an fp32 fma chain), at 16x the fp32 matrix rate, which pays for dense 16 x 32
+ * blocks of A and 256-row tiles (3.1 staged source rows per result row instead of 5.8).  Arrays:
+ *   hdr[n_tiles][32]                         first row of each of the 8 waves, rows of each wave, staged rows U
+ *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
+ *   afr[n_tiles][8][chunks][4][64][8] fp16   A fragments in lane order (2 * half + piece)
+ *   adr[n_tiles][8][chunks][2][64]           per-lane plane byte address of the transpose reads
+ * with chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0; no halo
+ * source.  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
+ * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */
+int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const void* afr, const int32_t* adr,
+                       int32_t n_tiles,
+                       const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                       float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                       int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                       float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream);
+int32_t sgp_spmm_split_chunks(void);
+int32_t sgp_spmm_split_max_union(void);
+int32_t sgp_spmm_split_waves(void);
+
 /* Column-blocked hop for graphs without locality (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/colblock.py).  The columns are cut into n_blocks blocks of consecutive columns whose source
  * rows fit the L2 of an XCD; n_wg persistent workgroups (16 waves) each own a contiguous range of at

@@ -142,6 +142,39 @@ inline unsigned grid_for(long long work_items) {
 
 }  // namespace
 
+// max |x| over a strided [batch, n_rows, feat] view: one atomicMax on the bit pattern of the non-negative
+// maximum per workgroup (IEEE order = integer order for non-negative floats; NaN / inf bit patterns win, so a
+// non-finite input shows as a non-finite bound).  feat % 4 == 0 takes 16-byte loads.
+__global__ __launch_bounds__(256) void abs_max_kernel(const float* x, long long xrs, long long xbs, int n_rows,
+                                                      int batch, int feat, unsigned* out) {
+    const int b = blockIdx.y;
+    const float* xb = x + (long long)b * xbs;
+    unsigned m = 0;
+    if ((feat & 3) == 0) {
+        const int q = feat >> 2;
+        const long long total = (long long)n_rows * q;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long r = i / q; const int c = (int)(i - r * q);
+            const float4 v = *(const float4*)(xb + r * xrs + 4 * c);
+            m = max(m, __float_as_uint(fabsf(v.x))); m = max(m, __float_as_uint(fabsf(v.y)));
+            m = max(m, __float_as_uint(fabsf(v.z))); m = max(m, __float_as_uint(fabsf(v.w)));
+        }
+    } else {
+        const long long total = (long long)n_rows * feat;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const long long r = i / feat; const int c = (int)(i - r * feat);
+            m = max(m, __float_as_uint(fabsf(xb[r * xrs + c])));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(part[0], part[1]), max(part[2], part[3])));
+}
+
+
 extern "C" {
 
 int sgp_bcast_rows_f32(const float* src, float scale, float* Y, int64_t yrs, int64_t ybs,
@@ -235,6 +268,27 @@ int sgp_gather_rows_f32(const float* X, int64_t xrs, int64_t xbs,
         hipLaunchKernelGGL(gather_rows_kernel<1>, dim3(grid_for((long long)n_index * feat), batch), dim3(256),
                            0, s, X, xrs, xbs, step, node, n_index, out, ors, obs, feat);
     return sgp::check_launch("gather_rows");
+}
+
+int sgp_abs_max_f32(const float* X, int64_t xrs, int64_t xbs, int32_t n_rows, int32_t batch, int32_t feat,
+                    float* out, sgp_stream_t stream) {
+    SGP_REQUIRE(out, "sgp_abs_max_f32: null pointer");
+    SGP_REQUIRE(n_rows >= 0 && batch >= 0 && feat >= 0, "sgp_abs_max_f32: bad size");
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, 4, s);
+    if (e != hipSuccess) return sgp::fail((int)e, "sgp_abs_max_f32: %s", hipGetErrorString(e));
+    if (!n_rows || !batch || !feat) return 0;
+    SGP_REQUIRE(X, "sgp_abs_max_f32: null pointer");
+    const bool vec = (feat & 3) == 0 && sgp::aligned16(X) && xrs % 4 == 0 && xbs % 4 == 0;
+    SGP_REQUIRE(vec || (feat & 3) != 0, "sgp_abs_max_f32: widths that are multiples of 4 need 16-byte aligned rows");
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+        const int nb = batch - b0 < 65535 ? batch - b0 : 65535;
+        long long per = ((long long)n_rows * feat / (vec ? 4 : 1) + 256 * 8 - 1) / (256 * 8);
+        int gx = (int)(per < 1 ? 1 : per > 1024 ? 1024 : per);
+        hipLaunchKernelGGL(abs_max_kernel, dim3(gx, nb), dim3(256), 0, s, X + (long long)b0 * xbs, xrs, xbs,
+                               n_rows, nb, feat, (unsigned*)out);
+    }
+    return sgp::check_launch("sgp_abs_max_f32");
 }
 
 }  // extern "C"

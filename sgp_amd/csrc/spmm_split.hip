@@ -1,0 +1,344 @@
+// Split-fp16 hop: y[b] = A x[b] on the 16-bit matrix cores with fp32-equivalent results
+// (reference call site: lib/sgp_preprocessing.py:200-203, `x = adj @ x` per hop).  gfx950 / wave64 only.
+//
+// Why another hop kernel.  The exact-fp32 row-group kernels (spmm_res / spmm_mix) are bound by
+// the fp32 matrix rate (1 / 16 of the 16-bit rate): compute alone caps them at 0.34 of the HBM roofline, and
+// their 64-row tiles pull 5.8 staged rows per result row through the CU.  Here a value is carried as TWO fp16
+// pieces of its scaled self, v * s = hi + lo (22 significant bits; s a power of two that puts the data in the
+// middle of the fp16 range), and a product as hi*hi + hi*lo + lo*hi accumulated in fp32 by
+// v_mfma_f32_16x16x32_f16 -- measured against fp64 its error is BELOW that of an fp32 fma chain
+// (tools/ubench/f16split_test.hip: 0.9e-7 vs 1.6e-7 of the input scale over 128-term rows).  Dense 16 x 32
+// blocks of A at 16x the fp32 rate make 256-row tiles affordable: 3.1 staged rows per result row.
+//
+// Structure (plan: sgp_amd/splitplan.py):
+//   * a workgroup of 8 waves owns a tile of up to 8 x 32 consecutive rows for a chunk of time steps; wave w
+//     owns up to 32 rows (two 16-row halves) and NCH chunks of 32 columns -- its A fragments (hi / lo piece,
+//     both halves, 16 VGPRs per chunk) are loaded once and stay in registers for the whole chunk;
+//   * a unit = (time step, 16-feature slice).  The tile's distinct source rows (<= SMAX) are loaded as 64-byte
+//     pieces (global_load_dwordx4, 4 lanes per row), scaled, split and written to LDS as two planes of fp16
+//     rows (32 B per row and plane) while the MFMAs of the previous unit run; two LDS buffers, one barrier per unit;
+//   * B operands come straight out of the row-major planes with ds_read_b64_tr_b16 (per-lane ROW addresses: the
+//     4 rows a 16-lane group reads may lie anywhere), 4 reads + 6 MFMAs per chunk;
+//   * results leave as 64-byte row pieces (16 lanes x 4 B) one unit later, in front of the next loads
+//     (stores and loads share vmcnt; this order lets one vmcnt(0) in front of the conversion cover both).
+// Limits checked by the planner: a wave's rows touch <= 32 NCH distinct columns, a tile <= SMAX; feat % 16 == 0;
+// |x| * x_scale and |a| * w_scale must stay below 65504 (the host picks the scales from bounds).
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef short s8v __attribute__((ext_vector_type(8)));
+using sgp::f32x4;
+
+constexpr int NW = 8;                        // waves per workgroup
+constexpr int NCH = 9;                       // resident 32-column chunks per wave
+constexpr int SMAX = 768;                    // staged rows per tile
+constexpr int NLD = SMAX / (16 * NW);        // 6 LDS-DMA instructions per wave and unit (16 rows each)
+constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
+constexpr int NBUF = 3;                      // landing | being converted | being multiplied
+constexpr int HDR = 32;                      // ints per tile header: row0[8], cnt[8], U, pad
+
+struct SplitArgs {
+    const int* hdr; const int* ucol; const h8* afr; const int* adr;
+    int n_tiles, tiles_per_xcd;
+    const float* X; long long xrs, xbs;
+    float* Y; long long yrs, ybs;
+    int batch, nslice, t_chunk;
+    float x_scale, inv_scale;
+    unsigned long long* dbg;                 // mode 256: per-wave s_memtime stamps of workgroup 0
+    int mode;                                // ablations (SGP_SPLIT_ABL): 1 no loads, 2 no MFMAs, 4 no stores, 8 no conversion, 16 all tiles of an XCD stage the same rows (upper bound of L2 sharing), 32 unpaired stores
+};
+
+// B operand of one chunk: four transpose reads (hi / lo piece x rows k = 0..3 / 4..7 of every lane group).  Issued
+// from asm so that the wait in front of the MFMAs can be COUNTED (LDS returns in order): hipcc waits lgkmcnt(0),
+// i.e. also for the reads of the next chunk that were just issued.
+struct BOp { s4v h0, h1, l0, l1; };
+__device__ __forceinline__ void tr_issue(BOp& b, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
+                 "ds_read_b64_tr_b16 %2, %4 offset:256\n\tds_read_b64_tr_b16 %3, %5 offset:256"
+                 : "=&v"(b.h0), "=&v"(b.h1), "=&v"(b.l0), "=&v"(b.l1) : "v"(a0), "v"(a1) : "memory");
+}
+template <int N> __device__ __forceinline__ void tr_wait(BOp& b) {
+    asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b.h0), "+v"(b.h1), "+v"(b.l0), "+v"(b.l1) : "n"(N));
+}
+__device__ __forceinline__ h8 cat8(s4v x, s4v y) {
+    return __builtin_bit_cast(h8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+// 64 lanes x 16 B from per-lane global addresses (sbase + voff) straight into LDS at lds_off + 16 * lane
+__device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(sbase), "s"(lds_off) : "memory");   // m0 is a reserved register: hipcc rejects it in a clobber list and never keeps a value in it across an asm
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm_n(int n) {       // n is wave-uniform, 0 .. NLD
+    switch (n) {
+        case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break;
+        case 3: wait_vm<3>(); break; case 4: wait_vm<4>(); break; case 5: wait_vm<5>(); break;
+        default: wait_vm<6>(); break;
+    }
+}
+static_assert(NCH >= 2, "the operand ring is primed with two chunks");
+static_assert(NLD == 6, "wait_vm_n covers 0 .. 6 outstanding pieces");
+
+// v * s = hi + lo: hi by truncation (v_cvt_pkrtz: the remainder is then exact in fp32), lo rounded
+__device__ __forceinline__ void split4(const f32x4 v, const float s, uint2& hi, uint2& lo) {
+    const float a0 = v[0] * s, a1 = v[1] * s, a2 = v[2] * s, a3 = v[3] * s;
+    const h2 h01 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a0, a1));
+    const h2 h23 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a2, a3));
+    h2 l01, l23;
+    l01[0] = (_Float16)(a0 - (float)h01[0]); l01[1] = (_Float16)(a1 - (float)h01[1]);
+    l23[0] = (_Float16)(a2 - (float)h23[0]); l23[1] = (_Float16)(a3 - (float)h23[1]);
+    hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
+    lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
+}
+
+__global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    // XCD x (= blockIdx % 8) walks its own contiguous range of tiles, time chunk by time chunk, so the 32
+    // workgroups an XCD runs side by side are neighbouring tiles of the same steps (their staged rows overlap)
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int tile = xcd * a.tiles_per_xcd + j % a.tiles_per_xcd;
+    const int tchunk = j / a.tiles_per_xcd;
+    if (tile >= a.n_tiles) return;
+    const int t_begin = tchunk * a.t_chunk;
+    const int t_end = min(a.batch, t_begin + a.t_chunk);
+    if (t_begin >= t_end) return;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int* hd = a.hdr + (size_t)tile * HDR;
+    const int row0 = __builtin_amdgcn_readfirstlane(hd[wave]);
+    const int cnt = __builtin_amdgcn_readfirstlane(hd[NW + wave]);
+    const int src_tile = (a.mode & 16) ? xcd * a.tiles_per_xcd : tile;   // 16: every tile of an XCD stages the same rows
+    const int nU = __builtin_amdgcn_readfirstlane(a.hdr[(size_t)src_tile * HDR + 2 * NW]);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+
+    // ---- resident plan: A fragments and per-lane row addresses of the transpose reads
+    h8 af[NCH][4];
+    int ad[NCH][2];
+    {
+        const h8* ap = a.afr + ((size_t)(tile * NW + wave) * NCH * 4) * 64 + lane;
+        const int* dp = a.adr + ((size_t)(tile * NW + wave) * NCH * 2) * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) af[c][q] = ap[(c * 4 + q) * 64];
+            ad[c][0] = dp[(c * 2 + 0) * 64];
+            ad[c][1] = dp[(c * 2 + 1) * 64];
+        }
+    }
+    // ---- pieces this wave stages: instruction i covers staged rows (i NW + wave) 16 .. + 15, 4 lanes per row;
+    // lanes past the tile's last row re-load row 0 (a valid address; their LDS rows are never read)
+    unsigned xoff[NLD];
+    const int* uc = a.ucol + (size_t)src_tile * SMAX;
+    int nld = 0;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int s = (i * NW + wave) * 16 + (lane >> 2);
+        const int c = uc[s < nU ? s : 0];
+        xoff[i] = (unsigned)(c * a.xrs * 4 + (lane & 3) * 16);
+        if ((i * NW + wave) * 16 < nU) nld = i + 1;
+    }
+    wait_vm<0>();                                             // the plan loads above: from here on vmcnt is counted by hand
+    // own rows inside a buffer: row s = (i NW + wave) 16 + lane / 4 at s * 64, this lane's 16 B at + (lane & 3) * 16
+    const int own = wave * 1024 + lane * 16;
+    // converted layout, in place: a group of 8 staged rows (512 B) keeps the hi pieces of row r at 32 r and the lo
+    // pieces at 256 + 32 r -- eight consecutive rows cover all 64 banks with either piece, and lo = hi + 256 is an
+    // immediate offset of the transpose reads.  A wave instruction covers two whole groups, so every read of a
+    // group has returned before its first write goes out.
+    const int cv_off = wave * 1024 + (lane >> 5) * 512 + ((lane >> 2) & 7) * 32 + (lane & 3) * 8;
+
+    auto issue_dma = [&](int t, int sl, int buf) {
+        const float* xb = (a.mode & 64) ? a.X : a.X + (long long)t * a.xbs + sl * 16;   // 64: always step 0 (all L2 hits)
+        const unsigned base = lds0 + buf * BUF + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (i < nld) dma16(xoff[i], xb, base + i * (NW * 1024));
+    };
+    auto convert = [&](int buf) {
+        char* rb = lds + buf * BUF;
+        // all NLD pieces, also those this wave did not request (rows past the tile's last: stale bytes that no
+        // transpose read addresses): no branches, so the six reads go out together
+        f32x4 v[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) v[i] = *(const f32x4*)(rb + own + i * (NW * 1024));
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            uint2 hi, lo;
+            split4(v[i], a.x_scale, hi, lo);
+            *(uint2*)(rb + cv_off + i * (NW * 1024)) = hi;
+            *(uint2*)(rb + cv_off + i * (NW * 1024) + 256) = lo;
+        }
+    };
+    // 4 x 4 transpose inside every quad of lanes (two DPP butterfly stages): lane 4 q + j ends up with row
+    // 4 g + j, features 4 q .. 4 q + 3, i.e. one 16-byte piece of a result row -- 2 stores per unit instead of 8
+    auto quad_transpose = [&](f32x4& r) {
+        const bool b0 = lane & 1, b1 = lane & 2;
+        auto swap1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); };
+        auto swap2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)); };
+        const float ra = swap1(b0 ? r[0] : r[1]), rb = swap1(b0 ? r[2] : r[3]);
+        const float a0 = b0 ? ra : r[0], a1 = b0 ? r[1] : ra, a2 = b0 ? rb : r[2], a3 = b0 ? r[3] : rb;
+        const float rc = swap2(b1 ? a0 : a2), rd = swap2(b1 ? a1 : a3);
+        r[0] = b1 ? rc : a0; r[1] = b1 ? rd : a1; r[2] = b1 ? a2 : rc; r[3] = b1 ? a3 : rd;
+    };
+    const int my_slot = 4 * (lane >> 4) + (lane & 3);
+    const long long yoff = (long long)(row0 + my_slot) * a.yrs + 4 * ((lane >> 2) & 3);
+
+    const int n_units = (t_end - t_begin) * a.nslice;
+    // DMA cursor (two units ahead of the multiply) and multiply cursor
+    int dt = t_begin, dsl = 0;
+    auto advance = [&](int& t, int& sl) { if (++sl == a.nslice) { sl = 0; ++t; } };
+
+    issue_dma(dt, dsl, 0); advance(dt, dsl);
+    if (n_units > 1) { issue_dma(dt, dsl, 1); advance(dt, dsl); wait_vm_n(nld); } else wait_vm<0>();
+    convert(0);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+    int t = t_begin, sl = 0, cur = 0;
+    const bool late = (wave >> 2) != 0 && !(a.mode & 128);    // 128: every wave multiplies first
+    f32x4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
+    auto stamp = [&](int u, int k) {
+        if ((a.mode & 256) && blockIdx.x == 0 && lane == 0 && u >= 16 && u < 24)
+            a.dbg[((u - 16) * NW + wave) * 8 + k] = __builtin_amdgcn_s_memtime();
+    };
+    for (int u = 0; u < n_units; ++u) {
+        stamp(u, 0);
+        const int nxt = cur == NBUF - 1 ? 0 : cur + 1;
+        const int nn = nxt == NBUF - 1 ? 0 : nxt + 1;
+        const bool more2 = u + 2 < n_units;
+        if (more2 && !(a.mode & 1)) { issue_dma(dt, dsl, nn); advance(dt, dsl); }
+
+        stamp(u, 1);
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+        auto stage_next = [&]() {
+            if (u + 1 < n_units) {
+                // the pieces of unit u + 1 were requested a whole unit ago; only the nld newest (unit u + 2) may stay in flight
+                if (more2 && !(a.mode & 1)) wait_vm_n(nld); else wait_vm<0>();
+                if (!(a.mode & 8)) convert(nxt);
+            }
+        };
+        // the two waves of a SIMD (w and w + 4) take the unit's two phases in opposite order: one multiplies while the
+        // other converts (both orders are legal: unit u was converted before the last barrier, unit u + 1 landed a unit ago)
+        if (late) stage_next();
+        stamp(u, 2);
+        if (!(a.mode & 2)) {
+            // operands of chunk c + 1 are requested before the MFMAs of chunk c issue
+            const unsigned cbo = lds0 + cur * BUF;
+            BOp b[3];                                         // two chunks in flight beside the one being multiplied
+            tr_issue(b[0], cbo + ad[0][0], cbo + ad[0][1]);
+            tr_issue(b[1], cbo + ad[1][0], cbo + ad[1][1]);
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                BOp& x = b[c % 3];
+                if (c + 2 < NCH) { tr_issue(b[(c + 2) % 3], cbo + ad[c + 2][0], cbo + ad[c + 2][1]); tr_wait<8>(x); }
+                else if (c + 1 < NCH) tr_wait<4>(x);
+                else tr_wait<0>(x);
+                const h8 bh = cat8(x.h0, x.h1), bl = cat8(x.l0, x.l1);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bh, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bl, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][3], bh, acc1, 0, 0, 0);
+            }
+        }
+        stamp(u, 3);
+        if (!late) stage_next();
+        stamp(u, 4);
+        if (!(a.mode & 4)) {
+            f32x4 r0 = acc0 * a.inv_scale, r1 = acc1 * a.inv_scale;
+            quad_transpose(r0);
+            quad_transpose(r1);
+            // an even slice waits for its odd neighbour: the two 64-byte halves of a 128-byte line leave together
+            if (!(sl & 1) && sl + 1 < a.nslice && !(a.mode & 32)) {
+                h0 = r0; h1 = r1;
+            } else {
+                float* yb = a.Y + (long long)t * a.ybs + sl * 16 + yoff;
+                if ((sl & 1) && !(a.mode & 32)) {
+                    if (my_slot < cnt) { *(f32x4*)(yb - 16) = h0; *(f32x4*)yb = r0; }
+                    if (16 + my_slot < cnt) { *(f32x4*)(yb + 16 * a.yrs - 16) = h1; *(f32x4*)(yb + 16 * a.yrs) = r1; }
+                } else {
+                    if (my_slot < cnt) *(f32x4*)yb = r0;
+                    if (16 + my_slot < cnt) *(f32x4*)(yb + 16 * a.yrs) = r1;
+                }
+            }
+        }
+        stamp(u, 5);
+        advance(t, sl);
+        cur = nxt;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        stamp(u, 6);
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t sgp_spmm_split_chunks(void) { return NCH; }
+extern "C" int32_t sgp_spmm_split_max_union(void) { return SMAX; }
+extern "C" int32_t sgp_spmm_split_waves(void) { return NW; }
+
+extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const void* afr, const int32_t* adr,
+                                  int32_t n_tiles,
+                                  const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                                  float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                                  int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                                  float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream) {
+    SGP_REQUIRE(n_tiles >= 0 && batch >= 0 && n_rows >= 0 && n_cols >= 0, "spmm_split: negative size");
+    if (n_tiles == 0 || batch == 0 || n_rows == 0) return 0;
+    SGP_REQUIRE(hdr && ucol && afr && adr && X && Y, "spmm_split: null pointer");
+    SGP_REQUIRE(feat > 0 && feat % 16 == 0, "spmm_split: feat = %d is not a multiple of 16", feat);
+    SGP_REQUIRE(sgp::aligned16(X) && x_row_stride % 4 == 0 && x_batch_stride % 4 == 0 &&
+                sgp::aligned16(Y) && y_row_stride % 4 == 0 && y_batch_stride % 4 == 0,
+                "spmm_split: X and Y rows must be 16-byte aligned");
+    SGP_REQUIRE((long long)n_cols * x_row_stride < (1ll << 29) && (long long)n_rows * y_row_stride < (1ll << 40),
+                "spmm_split: source rows beyond 32-bit byte offsets");
+    SGP_REQUIRE(x_scale > 0.f && w_scale > 0.f, "spmm_split: scales must be positive");
+    SplitArgs a;
+    a.hdr = hdr; a.ucol = ucol; a.afr = (const h8*)afr; a.adr = adr;
+    a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
+    a.X = X; a.xrs = x_row_stride; a.xbs = x_batch_stride;
+    a.Y = Y; a.yrs = y_row_stride; a.ybs = y_batch_stride;
+    a.batch = batch; a.nslice = feat / 16;
+    if (t_chunk <= 0) {
+        // enough workgroups for ~8 rounds of the chip, chunks of at least 8 steps (the plan load is ~4 steps' worth)
+        t_chunk = 64;
+        while (t_chunk > 8 && (long long)n_tiles * ((batch + t_chunk - 1) / t_chunk) < 2048) t_chunk >>= 1;
+    }
+    a.t_chunk = t_chunk;
+    a.x_scale = x_scale; a.inv_scale = 1.f / (x_scale * w_scale);
+    static const int abl = getenv("SGP_SPLIT_ABL") ? atoi(getenv("SGP_SPLIT_ABL")) : 0;
+    a.mode = abl;
+    a.dbg = nullptr;
+    if (abl & 256) { if (hipMalloc(&a.dbg, 8 * NW * 8 * 8) != hipSuccess) return sgp::fail(SGP_EINVAL, "dbg alloc"); (void)hipMemset(a.dbg, 0, 8 * NW * 8 * 8); }
+    const int n_tchunks = (batch + t_chunk - 1) / t_chunk;
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev < 64 && !attr_set[dev]) {
+        hipError_t e = hipFuncSetAttribute((const void*)spmm_split, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * BUF);
+        if (e != hipSuccess) return sgp::fail((int)e, "spmm_split: LDS attribute: %s", hipGetErrorString(e));
+        attr_set[dev] = true;
+    }
+    const unsigned grid = 8u * (unsigned)a.tiles_per_xcd * (unsigned)n_tchunks;
+    hipLaunchKernelGGL(spmm_split, dim3(grid), dim3(NW * 64), NBUF * BUF, (hipStream_t)stream, a);
+    if (abl & 256) {
+        unsigned long long h[8 * NW * 8];
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
+        (void)hipFree(a.dbg);
+        printf("spmm_split timeline (cycles since the unit's top; columns: dma issued | first phase done | MFMAs / second phase | .. | stores | barrier)\n");
+        for (int u = 0; u < 8; ++u) for (int w = 0; w < NW; ++w) {
+            const unsigned long long* r = h + (u * NW + w) * 8;
+            printf("  unit %d wave %d: top %llu |", u, w, r[0] - h[0]);
+            for (int k = 1; k < 7; ++k) printf(" %6lld", (long long)(r[k] - r[0]));
+            printf("\n");
+        }
+    }
+    return sgp::check_launch("spmm_split");
+}

@@ -269,10 +269,54 @@ class ShiftOperator:
             self._plans[key] = plan
         return self._plans[key]
 
-    def propagate(self, x, y, force=None, halo=None):
+    def split_plan(self, device):
+        """Plan of the split-fp16 hop (``sgp_amd.splitplan``, kernel ``sgp_spmm_split_f32``) or None: every
+        row must fit a wave's column budget (<= 32 * chunks distinct columns) -- graphs with very long rows
+        keep the exact-fp32 kernels."""
+        key = ("split", str(device))
+        if key not in self._plans:
+            plan = None
+            if self.num_cols == self.num_nodes and self.nnz() > 0:
+                from . import hip, splitplan
+                lib = hip.load()
+                plan = splitplan.build_split_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                                  self.num_nodes, self.num_cols,
+                                                  waves=lib.sgp_spmm_split_waves(),
+                                                  chunks=lib.sgp_spmm_split_chunks(),
+                                                  max_union=lib.sgp_spmm_split_max_union())
+                if plan is not None:
+                    plan = plan.to(device)
+            self._plans[key] = plan
+        return self._plans[key]
+
+    def split_eligible(self, x, y, halo=None):
+        """Whether ``propagate`` would pick the split-fp16 hop on its own for these operands (callers that
+        know a bound on |x| pass it; others let ``propagate`` measure one)."""
+        return (halo is None and os.environ.get("SGP_HOP", "split") == "split"
+                and self.num_cols == self.num_nodes and x.is_cuda
+                and x.shape[2] % 16 == 0 and x.shape[1] * max(x.stride(1), 1) < 2 ** 29
+                and x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+                and y.stride(1) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
+                and self.nnz() >= 8 * self.num_nodes and self.num_nodes >= 2048
+                and self.split_plan(x.device) is not None)
+
+    def norm_inf(self):
+        """max_i sum_j |a_ij|: |A x| <= norm_inf * max |x| (bound bookkeeping of the split-fp16 hop)."""
+        if not hasattr(self, "_norm_inf"):
+            rp = self.rowptr.long()
+            sums = torch.zeros(self.num_nodes, dtype=torch.float64)
+            if self.nnz():
+                sums.index_add_(0, torch.repeat_interleave(torch.arange(self.num_nodes), rp[1:] - rp[:-1]),
+                                self.val.double().abs())
+            self._norm_inf = float(sums.max()) if self.num_nodes else 0.0
+        return self._norm_inf
+
+    def propagate(self, x, y, force=None, halo=None, x_bound=None):
         """y[b] = A [x[b]; halo[b]] for strided [B, N, F] CUDA views (no allocation).
         ``halo[B, num_cols - num_nodes, F]`` (any strides) supplies the columns past the
-        owned rows for the local block of a node partition."""
+        owned rows for the local block of a node partition.  ``x_bound`` >= max |x| lets the split-fp16
+        hop pick its scale without measuring (the encoder knows it: bounded activations, row-stochastic
+        operators); None = measured by one reduction pass when that kernel is chosen."""
         from . import hip
         if (halo is None) != (self.num_cols == self.num_nodes):
             raise ValueError("halo rows are required exactly when num_cols > num_nodes")
@@ -293,6 +337,21 @@ class ShiftOperator:
         if not fits32 and force in (None, "csr"):
             plan = None
         halo_fits = fits32
+        # split-fp16 hop: first choice on one GPU where the plan exists; results agree with the
+        # exact-fp32 kernels to ~1e-7 of the operand scale.  SGP_HOP=exact keeps the fp32 matrix-core kernels.
+        if force == "split" or (force is None and self.split_eligible(x, y, halo)):
+            splan = self.split_plan(x.device) if halo is None and x.shape[2] % 16 == 0 else None
+            if splan is not None:
+                if x_bound is None:
+                    x_bound = hip.abs_max(x)
+                if x_bound == 0.0:
+                    x_bound = 1.0
+                if x_bound == x_bound and x_bound != float("inf"):
+                    self.last_kernel = "spmm_split"
+                    hip.spmm_split(splan, x, y, x_bound)
+                    return y
+            if force == "split":
+                raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")
         # mixed dense (16x16x4) / sparse (4x4x1) kernel: first choice where the planner finds enough shared
         # columns (k-NN-like graphs; measured 1-2 % faster than spmm_res on the 100-NN target graph);
         # SGP_SPMM_DEFAULT=res switches it off

@@ -133,6 +133,12 @@ SIGNATURES = {
     "sgp_grouped_linear_transpose_f32": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i32, c_p]),
     "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                     c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_abs_max_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p, c_p]),
+    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+                                          c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p]),
+    "sgp_spmm_split_chunks": (c_i32, []),
+    "sgp_spmm_split_max_union": (c_i32, []),
+    "sgp_spmm_split_waves": (c_i32, []),
     "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
                                              c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_spmm_colblock_rows_cap": (c_i32, []),
@@ -389,6 +395,35 @@ def spmm_blk(plan, x, y, halo=None, n_own=None):
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
         x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_blk_f32")
+
+
+@_on_device
+def abs_max(x):
+    """max |x| of a [B, N, D] view as a Python float (one device reduction + one 4-byte copy)."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    _check(lib.sgp_abs_max_f32(xp, xrs, xbs, x.shape[1], x.shape[0], x.shape[2], out.data_ptr(), _stream(x)),
+           "sgp_abs_max_f32")
+    return float(out.item())
+
+
+@_on_device
+def spmm_split(plan, x, y, x_bound, t_chunk=0):
+    """Split-fp16 hop (plan: sgp_amd.splitplan.SplitPlan on the device of ``x``).  ``x_bound`` >= max |x|
+    (the caller's guarantee: reservoir states of tanh / self_norm layers are bounded by 1, a hop multiplies
+    the bound by the operator's infinity norm); the scale puts it at 2^13..2^14 of the fp16 range."""
+    import math
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    yp, yrs, ybs = _view3(y, "y")
+    if not (x_bound > 0 and math.isfinite(x_bound)):
+        raise ValueError("spmm_split needs a finite positive bound on |x|")
+    x_scale = 2.0 ** math.floor(math.log2(16384.0 / x_bound))
+    _check(lib.sgp_spmm_split_f32(
+        plan.hdr.data_ptr(), plan.ucol.data_ptr(), plan.afr.data_ptr(), plan.adr.data_ptr(), plan.n_tiles,
+        xp, xrs, xbs, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2],
+        x_scale, plan.w_scale, t_chunk, _stream(x)), "sgp_spmm_split_f32")
 
 
 @_on_device

@@ -144,6 +144,12 @@ class SGPEncoder(nn.Module):
         hop_us = (self.sgp_encoder.num_blocks() - 1) * N * L * R * 8 / 4e6   # bytes of the hop blocks at ~4 TB/s
         return self.overlap_chunks if hop_us >= 0.25 * chain_us else 1
 
+    def _state_bound(self):
+        """Upper bound of |reservoir state| where the activation gives one: a leaky average of values in
+        [-1, 1] started from 0 stays in [-1, 1] (tanh; self_norm rows have unit 2-norm).  relu / identity
+        states are unbounded: None = the hop measures its operand."""
+        return 1.0 if self.reservoir.mode in ("tanh", "self_norm") else None
+
     def encode_device(self, x, ops, out=None, state=None, timeline=None):
         """x[T, N, F] CUDA float32 -> out[T, N, D_out] on the same device.  ``state`` [L, N, R]:
         reservoir state carried across calls (updated in place); ``timeline``: see
@@ -159,7 +165,7 @@ class SGPEncoder(nn.Module):
         if chunks <= 1:
             sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
             self.reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
-            self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums)
+            self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums, x_bound=self._state_bound())
             return out
         if state is None:
             state = torch.zeros(len(self.reservoir.reservoir_layers), N, self.reservoir.hidden_size,
@@ -178,7 +184,8 @@ class SGPEncoder(nn.Module):
             ready.record(main)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
-                self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline, col_sums=sums)
+                self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline, col_sums=sums,
+                                             x_bound=self._state_bound())
                 if sums is not None:
                     sums.record_stream(side)
         main.wait_stream(side)

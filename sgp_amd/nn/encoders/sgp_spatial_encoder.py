@@ -33,13 +33,13 @@ class SGPSpatialEncoder(nn.Module):
                                  add_self_loops=self.add_self_loops,
                                  bidirectional=self.bidirectional)
 
-    def encode_into(self, out, feat, ops, timeline=None, col_sums=None):
+    def encode_into(self, out, feat, ops, timeline=None, col_sums=None, x_bound=None):
         """Device path.  ``out[B, N, P * feat]`` with slot 0 already filled: run the hops
         and the global-mean block in place (sgp_spatial_encoder.py:22-35 without the
         ``torch.cat``).  ``col_sums`` [B, feat]: sums over the nodes of slot 0 when the producer
         already has them (``Reservoir.encode_into``): the global block is then written without
-        reading slot 0 again."""
-        propagate_into(out, feat, ops, self.receptive_field, timeline)
+        reading slot 0 again.  ``x_bound``: see ``propagate_into``."""
+        propagate_into(out, feat, ops, self.receptive_field, timeline, x_bound=x_bound)
         if self.global_attr:          # :32-34
             p = self.num_blocks() - 1
             slot = out[:, :, p * feat:(p + 1) * feat]

@@ -70,14 +70,17 @@ def spatial_operators(edge_index, edge_weight, num_nodes, undirected=False,
     return ops
 
 
-def propagate_into(out, feat, ops, k, timeline=None):
+def propagate_into(out, feat, ops, k, timeline=None, x_bound=None):
     """Fill hop slots of ``out[B, N, (1 + len(ops) * k) * feat]`` in place: slot 0 must
     already hold x; slot 1 + d*k + (h-1) receives ops[d]^h x.  No concatenation and no
     temporaries: every hop reads one slot and writes the next.  ``timeline``: a list that
     receives one (start, end) pair of ``hip.Event`` per hop launch, recorded on the stream the
-    hop runs on (bench.py's roofline timing)."""
+    hop runs on (bench.py's roofline timing).  ``x_bound`` >= max |slot 0| where the caller knows it
+    (bounded reservoir activations); the split-fp16 hop scales its operand by it, a hop multiplies
+    the bound by the operator's infinity norm, and an unknown bound is measured once per direction."""
     for d, op in enumerate(ops):
         src = out[:, :, 0:feat]
+        bound = x_bound
         for h in range(k):
             s = 1 + d * k + h
             dst = out[:, :, s * feat:(s + 1) * feat]
@@ -85,7 +88,12 @@ def propagate_into(out, feat, ops, k, timeline=None):
                 from . import hip
                 a, b = hip.Event(), hip.Event()
                 a.record()
-            op.propagate(src, dst)
+            if bound is None and k > 0 and op.split_eligible(src, dst):
+                from . import hip
+                bound = hip.abs_max(src)
+            op.propagate(src, dst, x_bound=bound)
+            if bound is not None:
+                bound = bound * max(op.norm_inf(), 1e-30) * (1 + 1e-6)
             if timeline is not None:
                 b.record()
                 timeline.append((a, b))

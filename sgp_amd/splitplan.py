@@ -1,0 +1,194 @@
+"""Host plan of ``sgp_spmm_split_f32`` (include/sgp_amd.h; kernel ``csrc/spmm_split.hip``): the split-fp16
+hop behind ``x = adj @ x`` (reference: lib/sgp_preprocessing.py:200-203).
+
+Rows are dealt in order to WAVES of at most 32 rows whose entries touch at most ``32 * chunks`` distinct
+columns, waves to TILES of at most ``waves`` waves whose rows touch at most ``max_union`` distinct columns
+(the tile's staged rows).  Per tile the kernel reads
+
+* ``hdr[tile]``            32 ints: first row of every wave, rows of every wave, staged rows U
+* ``ucol[tile, s]``        column (= source row) staged at position s, -1 beyond U
+* ``afr[tile, w, c, q]``   A fragments of ``v_mfma_f32_16x16x32_f16`` in lane order, q = 2 * half + piece:
+                           lane ``m + 16 g``, element e = piece of ``a[row slot 16 half + m, column k = 8 g + e of
+                           chunk c] * w_scale`` (piece 0: the value truncated to fp16, piece 1: the rounded rest)
+* ``adr[tile, w, c, j]``   per-lane byte address (inside a staged unit: a group of 8 staged rows is 512 bytes, the hi
+                           pieces of row r at ``32 r``, the lo pieces at ``256 + 32 r``) of the two transpose reads that fetch a chunk's B operand: lane
+                           ``i + 16 g`` points at the staged row of column ``k = 8 g + 4 j + i / 4``, bytes ``8 (i % 4)``
+
+Columns a wave does not use up to ``32 * chunks`` are padded with weight 0 and the address of staged row 0
+(finite data, so 0 * x stays 0).  Duplicate entries of a row are summed before the split.
+"""
+import numpy as np
+import torch
+
+
+class SplitPlan:
+    def __init__(self, hdr, ucol, afr, adr, n_tiles, n_rows, n_cols, w_scale, norm_inf, stats):
+        self.hdr, self.ucol, self.afr, self.adr = hdr, ucol, afr, adr
+        self.n_tiles, self.n_rows, self.n_cols = n_tiles, n_rows, n_cols
+        self.w_scale, self.norm_inf, self.stats = w_scale, norm_inf, stats
+
+    def to(self, device):
+        return SplitPlan(self.hdr.to(device), self.ucol.to(device), self.afr.to(device), self.adr.to(device),
+                         self.n_tiles, self.n_rows, self.n_cols, self.w_scale, self.norm_inf, self.stats)
+
+
+def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=32):
+    """Greedy deal in row order.  Returns (wave_of_row, slot_of_row, tile_of_wave, first_row, rows) or None
+    when a single row exceeds a wave's column budget."""
+    cap = 32 * chunks
+    wmark = np.full(n_cols, -1, dtype=np.int64)
+    tmark = np.full(n_cols, -1, dtype=np.int64)
+    wave_of_row = np.empty(n_rows, dtype=np.int64)
+    slot_of_row = np.empty(n_rows, dtype=np.int64)
+    tile_of_wave, first_row, rows = [], [], []
+    wave, tile = -1, -1
+    w_rows = w_cols = t_cols = t_waves = 0
+
+    def open_wave(r, new_tile):
+        nonlocal wave, tile, w_rows, w_cols, t_cols, t_waves
+        wave += 1
+        if new_tile:
+            tile += 1
+            t_cols = t_waves = 0
+        t_waves += 1
+        w_rows = w_cols = 0
+        tile_of_wave.append(tile)
+        first_row.append(r)
+        rows.append(0)
+
+    for r in range(n_rows):
+        c = np.unique(col[rowptr[r]:rowptr[r + 1]])
+        if c.size > cap or c.size > max_union:
+            return None
+        if wave < 0:
+            open_wave(r, True)
+        new_w = int((wmark[c] != wave).sum())
+        new_t = int((tmark[c] != tile).sum())
+        need_wave = w_rows == rows_per_wave or w_cols + new_w > cap
+        if t_cols + new_t > max_union or (need_wave and t_waves == waves):
+            open_wave(r, True)
+            new_w = new_t = c.size
+        elif need_wave:
+            open_wave(r, False)
+            new_w = c.size
+        wmark[c] = wave
+        tmark[c] = tile
+        w_cols += new_w
+        t_cols += new_t
+        wave_of_row[r] = wave
+        slot_of_row[r] = w_rows
+        w_rows += 1
+        rows[wave] = w_rows
+    return (wave_of_row, slot_of_row, np.asarray(tile_of_wave, dtype=np.int64),
+            np.asarray(first_row, dtype=np.int64), np.asarray(rows, dtype=np.int64))
+
+
+def split_fp16(v):
+    """v (float32, already scaled) -> (hi, lo) fp16 pieces with hi + lo ~ v to 2^-22: hi truncated towards
+    zero (what ``v_cvt_pkrtz_f16_f32`` does on the device side of x), lo the rounded remainder."""
+    v = np.asarray(v, dtype=np.float32)
+    bits = v.view(np.uint32) & np.uint32(0xFFFFE000)        # keep 10 explicit mantissa bits
+    hi32 = bits.view(np.float32)
+    small = np.abs(v) < np.float32(2.0 ** -14)              # fp16 subnormal range: let the conversion round
+    hi32 = np.where(small, v.astype(np.float16).astype(np.float32), hi32)
+    hi = hi32.astype(np.float16)
+    lo = (v - hi.astype(np.float32)).astype(np.float16)
+    return hi, lo
+
+
+def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768):
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    val = np.asarray(val, dtype=np.float32)
+    if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
+        return None
+    deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union)
+    if deal is None:
+        return None
+    wave_of_row, slot_of_row, tile_of_wave, first_row, rows = deal
+    n_waves = tile_of_wave.size
+    n_tiles = int(tile_of_wave[-1]) + 1
+    first_wave_of_tile = np.searchsorted(tile_of_wave, np.arange(n_tiles))
+    w_in_tile = np.arange(n_waves) - first_wave_of_tile[tile_of_wave]
+
+    row_of_edge = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr[:n_rows + 1]))
+    e_wave = wave_of_row[row_of_edge]
+    e_tile = tile_of_wave[e_wave]
+    # staged position of every (tile, column)
+    tkey, tinv = np.unique(e_tile * n_cols + col, return_inverse=True)
+    t_of_key = tkey // n_cols
+    t_first = np.searchsorted(t_of_key, np.arange(n_tiles))
+    union = np.diff(np.append(t_first, tkey.size))
+    stage_of_key = np.arange(tkey.size) - t_first[t_of_key]
+    ucol = np.full((n_tiles, max_union), -1, dtype=np.int32)
+    ucol[t_of_key, stage_of_key] = (tkey % n_cols).astype(np.int32)
+    # position of every (wave, column) in the wave's column list
+    wkey, winv = np.unique(e_wave * n_cols + col, return_inverse=True)
+    w_of_key = wkey // n_cols
+    w_first = np.searchsorted(w_of_key, np.arange(n_waves))
+    pos_of_key = np.arange(wkey.size) - w_first[w_of_key]
+    assert int(pos_of_key.max()) < 32 * chunks and int(union.max()) <= max_union
+    stage_of_wkey = stage_of_key[np.searchsorted(tkey, tile_of_wave[w_of_key] * n_cols + wkey % n_cols)]
+
+    # addresses: staged row of (wave, chunk, k), 0 for padding
+    srow = np.zeros((n_waves, chunks * 32), dtype=np.int64)
+    srow[w_of_key, pos_of_key] = stage_of_wkey
+    srow = srow.reshape(n_waves, chunks, 4, 2, 4)           # [wave, chunk, g, j, i / 4]: k = 8 g + 4 j + i / 4
+    lane_i = np.arange(16)
+    sl = srow[:, :, :, :, lane_i >> 2]
+    a = (sl >> 3) * 512 + (sl & 7) * 32 + 8 * (lane_i & 3)               # [wave, chunk, g, j, i]: hi piece of the row
+    a = a.transpose(0, 1, 3, 2, 4).reshape(n_waves, chunks, 2, 64)       # lane = 16 g + i
+    adr = np.zeros((n_tiles, waves, chunks, 2, 64), dtype=np.int32)
+    adr[tile_of_wave, w_in_tile] = a
+
+    # A fragments: sum duplicates in fp32, scale, split
+    pos = pos_of_key[winv]
+    slot = slot_of_row[row_of_edge]
+    k = pos % 32
+    dense = np.zeros((n_waves, chunks, 2, 64, 8), dtype=np.float32)      # [wave, chunk, half, lane, e]
+    np.add.at(dense, (e_wave, pos // 32, slot // 16, (slot % 16) + 16 * (k // 8), k % 8), val)
+    amax = float(np.abs(dense).max())                                    # after the duplicates were summed
+    w_scale = float(2.0 ** np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
+    hi, lo = split_fp16(dense * np.float32(w_scale))
+    afr = np.zeros((n_tiles, waves, chunks, 4, 64, 8), dtype=np.float16)
+    afr[tile_of_wave, w_in_tile, :, 0::2] = hi
+    afr[tile_of_wave, w_in_tile, :, 1::2] = lo
+
+    hdr = np.zeros((n_tiles, 32), dtype=np.int32)
+    hdr[tile_of_wave, w_in_tile] = first_row
+    hdr[tile_of_wave, waves + w_in_tile] = rows
+    hdr[:, 2 * waves] = union
+    rowsum = np.zeros(n_rows, dtype=np.float64)
+    np.add.at(rowsum, row_of_edge, np.abs(val.astype(np.float64)))
+    stats = dict(tiles=n_tiles, waves=n_waves, rows_per_wave=float(rows.mean()),
+                 rows_per_tile=float(n_rows / n_tiles), staged_per_row=float(union.sum() / n_rows),
+                 chunk_fill=float(wkey.size / (n_waves * chunks * 32)), max_union=int(union.max()))
+    return SplitPlan(torch.from_numpy(hdr), torch.from_numpy(ucol), torch.from_numpy(afr), torch.from_numpy(adr),
+                     n_tiles, n_rows, n_cols, w_scale, float(rowsum.max()), stats)
+
+
+def plan_matrix(plan, n_rows, n_cols):
+    """Dense matrix a plan encodes (hi + lo pieces, unscaled): test helper."""
+    hdr, ucol = plan.hdr.numpy(), plan.ucol.numpy()
+    afr, adr = plan.afr.numpy().astype(np.float64), plan.adr.numpy()
+    waves, chunks = afr.shape[1], afr.shape[2]
+    out = np.zeros((n_rows, n_cols))
+    for t in range(plan.n_tiles):
+        for w in range(waves):
+            row0, cnt = int(hdr[t, w]), int(hdr[t, waves + w])
+            if cnt == 0:
+                continue
+            for c in range(chunks):
+                for lane in range(64):
+                    m, g = lane & 15, lane >> 4
+                    for e in range(8):
+                        kk = 8 * g + e
+                        j, i4 = (kk % 8) // 4, kk % 4
+                        src_lane = 16 * g + 4 * i4                      # any lane with i / 4 == i4
+                        a_ = int(adr[t, w, c, j, src_lane])
+                        s = (a_ // 512) * 8 + (a_ % 512) // 32
+                        for half in range(2):
+                            v = afr[t, w, c, 2 * half, lane, e] + afr[t, w, c, 2 * half + 1, lane, e]
+                            if v != 0.0:
+                                out[row0 + 16 * half + m, int(ucol[t, s])] += v / plan.w_scale
+    return out

@@ -1,0 +1,107 @@
+"""Host plan of the split-fp16 hop (``sgp_amd/splitplan.py``; reference product: ``x = adj @ x``,
+lib/sgp_preprocessing.py:200-203): the plan arrays, read back the way the kernel reads them, are the
+operator (to the 2^-22 of the two fp16 pieces); the deal respects every limit the kernel assumes."""
+import numpy as np
+import pytest
+import torch
+
+from sgp_amd import graph, splitplan, synthetic
+
+LIM = dict(waves=8, chunks=9, max_union=768)
+
+
+def _op(ei, ew, n):
+    return graph.ShiftOperator.from_edges(ei, ew, n)
+
+
+def _plan(op, **kw):
+    return splitplan.build_split_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), op.num_nodes,
+                                      op.num_cols, **{**LIM, **kw})
+
+
+def _check_limits(plan, n_rows, waves=8, chunks=9, max_union=768):
+    hdr = plan.hdr.numpy()
+    row0, cnt, union = hdr[:, :waves], hdr[:, waves:2 * waves], hdr[:, 2 * waves]
+    assert cnt.max() <= 32 and cnt.min() >= 0 and union.max() <= max_union
+    assert int(cnt.sum()) == n_rows
+    # waves cover the rows once, in order
+    flat = [(int(r), int(c)) for r, c in zip(row0.reshape(-1), cnt.reshape(-1)) if c > 0]
+    nxt = 0
+    for r, c in flat:
+        assert r == nxt
+        nxt = r + c
+    assert nxt == n_rows
+    ucol = plan.ucol.numpy()
+    for t in range(plan.n_tiles):
+        u = int(union[t])
+        assert (ucol[t, :u] >= 0).all() and (ucol[t, u:] == -1).all()
+        assert len(np.unique(ucol[t, :u])) == u
+    adr = plan.adr.numpy()
+    srow = (adr // 512) * 8 + (adr % 512) // 32
+    assert (srow < np.maximum(union, 1)[:, None, None, None, None]).all()     # every address is a staged row
+    used = cnt > 0
+    assert ((adr[used] % 32) // 8 == (np.arange(64) & 3)).all()
+
+
+@pytest.mark.parametrize("n,k", [(700, 20), (500, 100), (300, 7), (1300, 60)])
+def test_plan_is_the_operator(n, k):
+    ei, ew, _ = synthetic.knn_graph(n, k, seed=3)
+    op = _op(ei, ew, n)
+    plan = _plan(op)
+    assert plan is not None
+    _check_limits(plan, n)
+    dense = op.to_dense().numpy().astype(np.float64)
+    got = splitplan.plan_matrix(plan, n, n)
+    assert np.abs(got - dense).max() <= 2.0 ** -21 * np.abs(dense).max()
+    assert abs(plan.norm_inf - np.abs(dense).sum(1).max()) < 1e-6
+
+
+def test_duplicates_empty_rows_and_ragged_degrees():
+    rng = np.random.default_rng(0)
+    n = 400
+    deg = rng.integers(0, 50, n)
+    deg[::9] = 0
+    tgt = np.repeat(np.arange(n), deg)
+    src = np.clip(tgt + rng.integers(-30, 31, tgt.size), 0, n - 1)           # duplicates are likely
+    ei = torch.from_numpy(np.stack([src, tgt]))
+    ew = torch.from_numpy(rng.random(tgt.size).astype(np.float32) + 0.1)
+    rowptr = np.concatenate([[0], np.cumsum(deg)])
+    order = np.argsort(tgt, kind="stable")
+    plan = splitplan.build_split_plan(rowptr, src[order], ew.numpy()[order], n, n, **LIM)   # un-coalesced CSR
+    assert plan is not None
+    _check_limits(plan, n)
+    dense = np.zeros((n, n))
+    np.add.at(dense, (tgt, src), ew.numpy().astype(np.float64))
+    got = splitplan.plan_matrix(plan, n, n)
+    assert np.abs(got - dense).max() <= 2.0 ** -20 * dense.max()
+
+
+def test_rows_beyond_a_waves_budget_have_no_plan():
+    n = 600
+    src = np.concatenate([np.arange(n), np.arange(300)])                      # row 5 touches 300 columns
+    tgt = np.concatenate([np.arange(n), np.full(300, 5)])
+    op = _op(torch.from_numpy(np.stack([src, tgt])), None, n)
+    assert _plan(op) is None
+    assert _plan(op, chunks=10) is not None
+
+
+def test_small_budgets_cut_waves_and_tiles():
+    ei, ew, _ = synthetic.knn_graph(900, 40, seed=5)
+    op = _op(ei, ew, 900)
+    plan = _plan(op, chunks=3, max_union=256)
+    assert plan is not None and plan.n_tiles > 4
+    _check_limits(plan, 900, chunks=3, max_union=256)
+    dense = op.to_dense().numpy().astype(np.float64)
+    assert np.abs(splitplan.plan_matrix(plan, 900, 900) - dense).max() <= 2.0 ** -21 * dense.max()
+
+
+def test_split_fp16_pieces():
+    rng = np.random.default_rng(1)
+    v = np.concatenate([rng.standard_normal(4096) * 1000, rng.standard_normal(4096) * 1e-3,
+                        [0.0, 16384.0, -16384.0, 2.0 ** -15, 6e-8]]).astype(np.float32)
+    hi, lo = splitplan.split_fp16(v)
+    back = hi.astype(np.float64) + lo.astype(np.float64)
+    err = np.abs(back - v.astype(np.float64))
+    assert (err <= np.maximum(np.abs(v) * 2.0 ** -21, 2.0 ** -25)).all()
+    big = np.abs(v) >= 2.0 ** -14
+    assert (np.abs(hi.astype(np.float32))[big] <= np.abs(v)[big]).all()      # truncated towards zero

@@ -147,6 +147,87 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
                       f"{w['T']} steps, best of 3 per thread setting"}
 
 
+HOP_ARITHMETIC = {
+    "spmm_split": "operands as two fp16 pieces of the scaled value (22 bits), products hi*hi + hi*lo + lo*hi on "
+                  "v_mfma_f32_16x16x32_f16, fp32 accumulation; max |error| vs fp64 ~1e-7 of the operand scale "
+                  "(tests/test_gpu_split.py); the exact-fp32 kernel is timed in roofline_exact_fp32",
+}
+
+
+def exact_hop_line(op, out, d_h, bts):
+    """The exact-fp32 hop kernel (SGP_HOP=exact's choice) on the same operand, slot 0 -> slot 1, three launches
+    after the timed region: the number the split-fp16 line is to be read against."""
+    src, dst = out[:, :, :d_h], out[:, :, d_h:2 * d_h]
+    saved = os.environ.get("SGP_HOP")
+    os.environ["SGP_HOP"] = "exact"
+    try:
+        op.propagate(src, dst)
+        ms = []
+        for _ in range(3):
+            a, b = hip.Event(), hip.Event()
+            a.record(); op.propagate(src, dst); b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_ms(b))
+        kernel = op.last_kernel
+    finally:
+        if saved is None:
+            os.environ.pop("SGP_HOP", None)
+        else:
+            os.environ["SGP_HOP"] = saved
+    per = sum(ms) / len(ms)
+    return {"kernel": kernel, "ms_per_launch": per, "achieved": bts / (per * 1e-3) / 1e9,
+            "frac": bts / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "launches_timed": len(ms)}
+
+
+def verify_output(enc, ops, x, out, w, T, tc, d_h):
+    """Check what the timed region left in ``out`` (the last time chunk when the embedding is produced in
+    chunks): every hop block at sampled steps -- first, around the kernels' chunk boundaries, middle, last --
+    against the generic CSR kernel (exact fp32) applied to the block it read; the global block against the
+    node mean; and the first steps of the encoder against the CPU oracle (north_star tolerance 1e-5)."""
+    from oracle import sgp_oracle as O
+    K, n_t = w["K"], out.shape[0]
+    steps = sorted({s for s in (0, 1, 31, 32, 63, 64, 65, n_t // 2, n_t - 2, n_t - 1) if 0 <= s < n_t})
+    idx = torch.tensor(steps, device=out.device)
+    worst, worst_rel = 0.0, 0.0
+    ok = True
+    for d, op in enumerate(ops):
+        for h in range(K):
+            blk = 1 + d * K + h
+            src = out[:, :, 0:d_h] if h == 0 else out[:, :, (blk - 1) * d_h:blk * d_h]
+            got = out[:, :, blk * d_h:(blk + 1) * d_h][idx]
+            ref = torch.empty_like(got)
+            op.propagate(src[idx].contiguous(), ref, force="csr")
+            err = float((got - ref).abs().max())
+            worst = max(worst, err)
+            worst_rel = max(worst_rel, float((got - ref).norm() / ref.norm().clamp_min(1e-30)))
+            ok = ok and bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-5))
+    rec = {"hop_blocks_vs_csr_kernel_max_abs": worst, "hop_blocks_rel_fro": worst_rel, "steps_checked": steps}
+    if w["glob"]:
+        p = out.shape[2] // d_h - 1
+        m = out[idx][:, :, :d_h].mean(1, keepdim=True)
+        e = float((out[idx][:, :, p * d_h:] - m).abs().max())
+        rec["global_block_max_abs"] = e
+        ok = ok and e <= 1e-5
+    # oracle: the first steps (the recurrence is causal, so a prefix of the sequence is a valid input)
+    n8 = min(8, T)
+    if tc < T:                                             # ring buffer holds the last chunk: encode the prefix again
+        head = enc.encode_device(x[:n8].contiguous(), ops)
+    else:
+        head = out[:n8]
+    torch.manual_seed(42)
+    layers = [dict(w_ih=l.w_ih.data.cpu(), w_hh=l.w_hh.data.cpu(), b_ih=l.b_ih.data.cpu(), alpha=float(l.alpha))
+              for l in enc.reservoir.reservoir_layers]
+    ei, ew = build_graph(w)
+    cops = O.shift_operators_csr(ei, ew, w["N"], bidirectional=w["bidir"])
+    ref = O.encoder_forward_prebuilt(x[:n8].cpu(), cops, layers, K, global_attr=w["glob"])
+    e = float((head.cpu() - ref).abs().max())
+    rec["first_steps_vs_cpu_oracle_max_abs"] = e
+    rec["oracle_steps"] = n8
+    ok = ok and bool(torch.allclose(head.cpu(), ref, rtol=1e-5, atol=1e-5))
+    rec["ok"] = ok
+    return rec
+
+
 def relaunch(args):
     """``python bench.py --gpus N`` without a launcher: run N ranks of this file under
     torch.distributed.run on 127.0.0.1 and pass their one JSON line through."""
@@ -175,6 +256,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="target", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the check of the timed output (sampled steps of every hop block against the "
+                         "generic CSR kernel on the block it read, first steps against the CPU oracle)")
+    ap.add_argument("--no-exact-line", action="store_true",
+                    help="skip timing the exact-fp32 hop kernel next to the default (split-fp16) one")
     ap.add_argument("--t-steps", type=int, default=0,
                     help="override the workload's number of time steps (functional tests of the big "
                          "configurations on a small box; the record says so)")
@@ -249,6 +335,8 @@ def main():
     out = torch.empty(tc, n_own, enc.output_size, device=dev)
     state = torch.zeros(L, n_own, R, device=dev) if tc < T else None
     for o in local_ops:                                     # plans + device CSR built once
+        if spatial is None and os.environ.get("SGP_HOP", "split") == "split":
+            o.split_plan(dev)
         o.tile_plan(d_h, dev)
         if os.environ.get("SGP_SPMM_DEFAULT", "mix") == "mix":
             o.mix_plan(d_h, dev)
@@ -310,7 +398,11 @@ def main():
             "metric": "encoded node-steps/sec", "value": value, "unit": "node-steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            "dtype": "f32" if os.environ.get("SGP_HOP", "split") != "split" or world > 1 else
+                     "f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per product, fp32 "
+                     "accumulation -- agrees with fp32 to ~1e-7 of the operand scale; reservoir: exact fp32 MFMA)",
+            "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={N} nodes, T={T} steps, F_in={F}, "
                                    f"reservoir {R}x{L}, K={K}, "
                                    f"{GRAPH_NAMES[w['graph']]}"
@@ -324,7 +416,8 @@ def main():
                        "gpus_visible": torch.cuda.device_count()},
         }
         if hop_ms:
-            per_launch = sum(a.elapsed_ms(b) for a, b in hop_ms) / len(hop_ms)
+            all_ms = sorted(a.elapsed_ms(b) for a, b in hop_ms)
+            per_launch = sum(all_ms) / len(all_ms)
             # one launch covers one time chunk -- or, on small graphs, one of the pieces the encoder
             # cuts it into to run the hops under the reservoir (SGPEncoder.encode_device)
             n_chunks = T // tc if T % tc == 0 else T // tc + 1
@@ -340,7 +433,13 @@ def main():
                                "traffic": traffic, "traffic_source": source,
                                "kernel": kernel,
                                "ms_per_launch": per_launch, "algorithmic_bytes": bts,
-                               "launches_per_hop": pieces}
+                               "launches_per_hop": pieces,
+                               # spread of the timed launches (lease-to-lease DVFS spread is ~5 %: DESIGN 6)
+                               "ms_min_median_max": [all_ms[0], all_ms[len(all_ms) // 2], all_ms[-1]],
+                               "launches_timed": len(all_ms),
+                               "arithmetic": HOP_ARITHMETIC.get(kernel, "exact fp32 products (fp32 MFMA / FMA)")}
+            if kernel == "spmm_split" and not args.no_exact_line:
+                rec["roofline_exact_fp32"] = exact_hop_line(ops[0], out, d_h, bts / pieces if pieces > 1 else bts)
         elif timeline:
             # rank 0's GPU: a hop of the local block = its launches over the time chunks; the
             # exchange of a hop = gather + all_to_all on the communication stream
@@ -370,6 +469,9 @@ def main():
                                 "note": "comm (row packing + all_to_all on its own stream) runs "
                                         "under the SpMM of the previous time chunk; the reservoir of "
                                         "the next time piece runs under both (third stream)"}
+        if world == 1 and spatial is None and not args.no_verify:
+            rec["verify"] = verify_output(enc, ops, x, out, w, T, tc, d_h)
+            rec["verified"] = bool(rec["verify"]["ok"])
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(w, ei, ew)
         os.write(json_fd, (json.dumps(rec) + "\n").encode())

@@ -335,10 +335,20 @@ class SGPEncoder(nn.Module):
     # D2H straight into the (registered) result tensor; False = pinned bounce slots + host memcpy
     register_output = True
 
-    def forward(self, x, edge_index, edge_weight, return_device=False, out=None):
+    def forward(self, x, edge_index, edge_weight, return_device=False, out=None, gpus=None):
         # x : [t n f]; ``return_device=True`` keeps the embedding of a host input on the GPU
         # (the next row f1 consumes it there: sgp_amd.datasets.IIDDataset); ``out``: host tensor
-        # [t, n, d_out] to fill (host inputs only; see encode_streamed)
+        # [t, n, d_out] to fill (host inputs only; see encode_streamed); ``gpus``: number of GPUs the
+        # graph is node-partitioned over (None: SGP_AMD_GPUS, default 1; 0 / "all": every visible GPU) --
+        # the call stays a single-process call on a host tensor, the ranks are started and joined inside
+        # (sgp_amd/multigpu.py)
+        from ... import multigpu
+        n_gpus = multigpu.resolve_gpus(gpus)
+        if n_gpus > 1:
+            if x.is_cuda or return_device:
+                raise ValueError("gpus > 1 takes a host tensor and returns a host tensor in the original node "
+                                 "order (device shards live in the rank processes)")
+            return multigpu.encode_multi_gpu(self, x, edge_index, edge_weight, n_gpus, out=out)
         dev = x.device
         ops = self.sgp_encoder.operators(x.size(-2), edge_index, edge_weight)
         xg = x.float()

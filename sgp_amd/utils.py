@@ -13,7 +13,7 @@ logger = logging.getLogger("sgp_amd")
 
 
 def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True,
-                   keep_raw=False, save_path=None, return_device=False):
+                   keep_raw=False, save_path=None, return_device=False, gpus=None):
     """lib/utils.py:10-47.  ``dataset`` is any object with the slice of the
     ``tsl.data.SpatioTemporalDataset`` interface the harness touches: ``exogenous``,
     ``get_tensors``, ``edge_index``, ``edge_weight``, ``add_exogenous``, ``set_input_map``.
@@ -26,7 +26,10 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     host round trip before the IID sampler); with ``save_path`` the encoder's
     constructor arguments, per-layer leaking rates and weights are written next to the tensor
     (``save_path + '.encoder.pt'``) so that the embedding can be re-derived (lib/utils.py:34-35
-    saves the tensor only, the random weights are lost)."""
+    saves the tensor only, the random weights are lost); ``gpus=N`` (default: SGP_AMD_GPUS, else 1)
+    node-partitions the graph over N GPUs behind the same single-process call (``sgp_amd/multigpu.py``:
+    one rank per GPU is started and joined inside, the embedding comes back as one host tensor in the
+    dataset's node order)."""
     exo_keys = _exogenous_to_encode(dataset, encode_exogenous)
     x, _ = dataset.get_tensors(['data'] + exo_keys, preprocess=True, cat_dim=-1)
     encoder = encoder_class(**encoder_kwargs)
@@ -36,7 +39,13 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
         from . import hip
         hip.require_gpu()
         x = x.cuda()
-    embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight)
+    from .multigpu import resolve_gpus
+    if resolve_gpus(gpus) > 1:
+        if return_device:
+            raise ValueError("return_device=True keeps ONE device tensor: use gpus=1")
+        embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight, gpus=gpus)
+    else:
+        embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight)
     seconds = int(time() - started)
     logger.info(f"Dataset encoded in {seconds // 60}:{seconds % 60:02d} minutes.")
 

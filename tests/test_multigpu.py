@@ -1,0 +1,134 @@
+"""Drop-in multi-GPU entry (``sgp_amd/multigpu.py``): ``SGPEncoder.forward(..., gpus=N)`` and
+``encode_dataset(..., gpus=N)`` -- the reference's single-process call (lib/utils.py:27-31) with the graph
+node-partitioned over N ranks behind it.  On the one-GPU test box the ranks share the device over gloo:
+the results must equal the single-GPU call."""
+import os
+
+import pytest
+import torch
+
+import sgp_amd
+from sgp_amd import multigpu, synthetic
+
+
+# ------------------------------------------------------------------ host logic (CPU)
+def test_resolve_gpus(monkeypatch):
+    monkeypatch.delenv("SGP_AMD_GPUS", raising=False)
+    assert multigpu.resolve_gpus(None) == 1
+    assert multigpu.resolve_gpus(4) == 4 and multigpu.resolve_gpus("2") == 2
+    monkeypatch.setenv("SGP_AMD_GPUS", "8")
+    assert multigpu.resolve_gpus(None) == 8
+    assert multigpu.resolve_gpus(1) == 1                        # the argument wins over the environment
+    assert multigpu.resolve_gpus("all") == max(1, torch.cuda.device_count())
+    with pytest.raises(ValueError):
+        multigpu.resolve_gpus(-1)
+
+
+def test_rank_rows_and_chunk_steps():
+    rows, n = multigpu.rank_rows([0, 5, 9], None, 1)
+    assert rows == slice(5, 9) and n == 4
+    order = torch.tensor([3, 1, 4, 0, 2, 8, 7, 6, 5])
+    rows, n = multigpu.rank_rows([0, 5, 9], order, 1)
+    assert n == 4 and rows.tolist() == [8, 7, 6, 5]
+    assert multigpu.chunk_steps(1000, 100, 3, 320, 10 ** 9) == 1000
+    assert multigpu.chunk_steps(1000, 100000, 64, 320, 2 * 10 ** 9) == 8          # the floor
+    tc = multigpu.chunk_steps(1000, 10000, 64, 320, 10 ** 9)
+    assert 8 <= tc < 1000 and 2 * tc * 10000 * 384 * 4 <= 10 ** 9
+
+
+def test_gpus_argument_is_rejected_where_it_cannot_be_served():
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=16, reservoir_layers=1, leaking_rate=.9,
+                             spectral_radius=.9, density=.7, input_scaling=1., receptive_field=1,
+                             bidirectional=False, alpha_decay=False, global_attr=False)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):                       # no GPU: the product path fails loudly
+            enc(torch.randn(4, 2, 3), ei, None, gpus=2)
+    with pytest.raises(ValueError):
+        enc(torch.randn(4, 2, 3), ei, None, gpus=2, return_device=True)
+
+
+# ------------------------------------------------------------------ GPU
+def _encoder(seed=3, **kw):
+    torch.manual_seed(seed)
+    args = dict(input_size=3, reservoir_size=32, reservoir_layers=2, leaking_rate=.9, spectral_radius=.9,
+                density=.7, input_scaling=1., receptive_field=3, bidirectional=True, alpha_decay=True,
+                global_attr=True)
+    args.update(kw)
+    return sgp_amd.SGPEncoder(**args)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_forward_gpus_equals_single_gpu(world):
+    """2 and 4 ranks (sharing the GPU over gloo on a one-GPU box) == the single-GPU forward, in the
+    ORIGINAL node order, through the same call."""
+    n, t = 3000, 40
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=5)
+    enc = _encoder()
+    x = torch.randn(t, n, 3, generator=torch.Generator().manual_seed(1))
+    ref = enc(x, ei, ew)
+    info = {}
+    y = multigpu.encode_multi_gpu(enc, x, ei, ew, world, info=info)
+    assert y.shape == ref.shape and not y.is_cuda
+    assert info["world"] == world and len(info["bounds"]) == world + 1 and info["halo_rows"] > 0
+    assert torch.allclose(y, ref, rtol=1e-6, atol=1e-6), float((y - ref).abs().max())
+    y2 = enc(x, ei, ew, gpus=world)                              # the drop-in spelling
+    assert torch.equal(y2, y)
+
+
+@pytest.mark.gpu
+def test_forward_gpus_renumbers_graphs_without_locality_and_chunks_time():
+    """Scrambled node labels: the ranks own a locality renumbering, the caller still gets its own node order;
+    a small device budget cuts the time axis (state carried on the devices)."""
+    n, t = 2400, 50
+    ei, ew, _ = synthetic.knn_graph(n, 12, seed=2)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1))
+    ei = perm[ei]
+    enc = _encoder(seed=8, reservoir_layers=1, bidirectional=False, alpha_decay=False)
+    x = torch.randn(t, n, 3, generator=torch.Generator().manual_seed(2))
+    ref = enc(x, ei, ew)
+    info = {}
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        y = multigpu.encode_multi_gpu(enc, x, ei, ew, 3, info=info, device_budget_bytes=6 * 2 ** 20)
+    assert info["reordered"] and info["t_chunk"] < t
+    assert torch.allclose(y, ref, rtol=1e-6, atol=1e-6), float((y - ref).abs().max())
+
+
+@pytest.mark.gpu
+def test_encode_dataset_gpus_on_the_reference_harness_fixture():
+    """``encode_dataset(..., gpus=2)`` on a g5 fixture (the reference's own harness output)."""
+    import numpy as np
+    from conftest import GOLDEN, golden_files
+    from test_host_logic import FakeDataset
+    name = golden_files("g5_")[0]
+    z = np.load(os.path.join(GOLDEN, name))
+    ds = FakeDataset(torch.from_numpy(z["data"]), torch.from_numpy(z["u"]),
+                     torch.from_numpy(z["edge_index"]), torch.from_numpy(z["edge_weight"]))
+    enc_exo = bool(z["encode_exogenous"])
+    kw = dict(input_size=3 if enc_exo else 1, reservoir_size=16, reservoir_layers=1, leaking_rate=.9,
+              spectral_radius=.9, density=.7, input_scaling=1., receptive_field=2, bidirectional=False,
+              alpha_decay=False, global_attr=False, add_self_loops=False, undirected=False)
+    torch.manual_seed(int(z["seed"]))
+    sgp_amd.encode_dataset(ds, sgp_amd.SGPEncoder, kw, encode_exogenous=enc_exo, keep_raw=bool(z["keep_raw"]),
+                           gpus=2)
+    got, want = ds._t["encoded_x"], torch.from_numpy(z["encoded_x"])
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+
+
+@pytest.mark.gpu
+def test_shard_dir_writes_rank_shards_instead_of_a_host_tensor(tmp_path):
+    n, t = 2200, 30
+    ei, ew, _ = synthetic.knn_graph(n, 20, seed=4)
+    enc = _encoder(seed=5, reservoir_layers=1)
+    x = torch.randn(t, n, 3, generator=torch.Generator().manual_seed(3))
+    ref = enc(x, ei, ew)
+    paths = multigpu.encode_multi_gpu(enc, x, ei, ew, 2, shard_dir=str(tmp_path), device_budget_bytes=8 * 2 ** 20)
+    assert len(paths) >= 4
+    got = torch.full_like(ref, float("nan"))
+    for p in paths:
+        s = torch.load(p)
+        got[s["t0"]:s["t0"] + s["steps"]].index_copy_(1, s["rows"], s["embedding"])
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)

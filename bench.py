@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import sgp_amd  # noqa: E402
-from sgp_amd import hip, partition, synthetic  # noqa: E402
+from sgp_amd import hip, partition, synthetic, tune  # noqa: E402
 from sgp_amd.sgp_preprocessing import spatial_operators  # noqa: E402
 
 WORKLOADS = {
@@ -155,11 +155,11 @@ HOP_ARITHMETIC = {
 
 
 def exact_hop_line(op, out, d_h, bts):
-    """The exact-fp32 hop kernel (SGP_HOP=exact's choice) on the same operand, slot 0 -> slot 1, three launches
+    """The exact-fp32 hop kernel (SGP_TUNE=hop=exact's choice) on the same operand, slot 0 -> slot 1, three launches
     after the timed region: the number the split-fp16 line is to be read against."""
     src, dst = out[:, :, :d_h], out[:, :, d_h:2 * d_h]
-    saved = os.environ.get("SGP_HOP")
-    os.environ["SGP_HOP"] = "exact"
+    saved = os.environ.get("SGP_TUNE")
+    os.environ["SGP_TUNE"] = "hop=exact" + ("," + saved if saved else "")
     try:
         op.propagate(src, dst)
         ms = []
@@ -171,9 +171,9 @@ def exact_hop_line(op, out, d_h, bts):
         kernel = op.last_kernel
     finally:
         if saved is None:
-            os.environ.pop("SGP_HOP", None)
+            os.environ.pop("SGP_TUNE", None)
         else:
-            os.environ["SGP_HOP"] = saved
+            os.environ["SGP_TUNE"] = saved
     per = sum(ms) / len(ms)
     return {"kernel": kernel, "ms_per_launch": per, "achieved": bts / (per * 1e-3) / 1e9,
             "frac": bts / (per * 1e-3) / 1e9 / HBM_PEAK_GBS, "unit": "GB/s", "launches_timed": len(ms)}
@@ -335,10 +335,10 @@ def main():
     out = torch.empty(tc, n_own, enc.output_size, device=dev)
     state = torch.zeros(L, n_own, R, device=dev) if tc < T else None
     for o in local_ops:                                     # plans + device CSR built once
-        if spatial is None and os.environ.get("SGP_HOP", "split") == "split":
+        if spatial is None and tune.get("hop", "split") == "split":
             o.split_plan(dev)
         o.tile_plan(d_h, dev)
-        if os.environ.get("SGP_SPMM_DEFAULT", "mix") == "mix":
+        if tune.get("exact", "mix") == "mix":
             o.mix_plan(d_h, dev)
         o.device_csr(dev)
 
@@ -399,7 +399,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if os.environ.get("SGP_HOP", "split") != "split" or world > 1 else
+            "dtype": "f32" if tune.get("hop", "split") != "split" or world > 1 else
                      "f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per product, fp32 "
                      "accumulation -- agrees with fp32 to ~1e-7 of the operand scale; reservoir: exact fp32 MFMA)",
             "data": "synthetic",

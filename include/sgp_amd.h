@@ -104,71 +104,32 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                        sgp_stream_t stream);
-/* Matrix-core row-group kernel.  Tiles and their distinct-column lists (tile_row_ptr / uptr /
- * ucol) are as above with tiles of at most 64 rows.  Every tile is cut into 16 groups of 4
- * rows (slots 4g .. 4g+3 of the tile, see rowmap).  A group's sorted column
- * union is dealt round-robin to 4 classes q; super-step s handles the s-th column of every
- * class with one v_mfma_f32_4x4x1_16b_f32 per feature (exact fp32).  The stream is stored 4
- * super-steps ("quad") at a time, gptr[k * 16 + g] .. gptr[k * 16 + g + 1] = quad range:
- *   gw  [quad][q][row i][4]   float   weight of row i for class q's column in super-steps 0..3
- *                                     of the quad (0 = row lacks the column / padding)
- *   gidx[quad][q][4]          int32   256 * index of that column in the tile's ucol list, i.e. the
- *                                     byte offset of its staged row in LDS (0 = padding)
- *   rowmap[64 * k + 4 g + i]  int32   output row of slot i of group g of tile k, -1 = empty
- *                                     (the host may permute rows inside a tile so that the 4
- *                                     rows of a group share most of their columns)
- * Limits: sgp_spmm_mfma_max_union() staged rows per tile, sgp_spmm_mfma_max_quads() quads per
- * tile (weights and indices are LDS-resident). */
-int sgp_spmm_mfma_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const int32_t* ucol,
-                      const int32_t* gptr, const int32_t* gidx, const float* gw,
-                      const int32_t* rowmap,
-                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
-                      const float* X, int64_t x_row_stride, int64_t x_batch_stride,
-                      const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
-                      int32_t n_own,
-                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
-                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                      sgp_stream_t stream);
-int32_t sgp_spmm_mfma_max_union(void);
-int32_t sgp_spmm_mfma_max_quads(void);
-
-/* Two-phase pipelined form of the row-group kernel (same tiles, groups, classes and arithmetic).
- * The tile's distinct-column list is cut at usplit[k] (a multiple of 4) into segment A (list
- * positions < usplit[k]) and segment B; a group's quads are stored A-part first and never mix
- * the segments: gptr[2 (16 k + g)] .. gptr[2 (16 k + g) + 1] = quads on segment A,
- * .. gptr[2 (16 k + g) + 2] = quads on segment B.  Per time step the kernel refills one segment
- * of the LDS stage by LDS-DMA (global_load_lds_dwordx4) while the matrix cores consume the other.
- * gsup[2 (16 k + g) + s] = ceil(columns of that range / 4): the kernel skips the padding of a
- * range's last quad in units of one super-step.  uptr / ucol list segment A first (padded to a
- * multiple of 4 entries), then segment B.  gidx / rowmap as for sgp_spmm_mfma_f32; gw is stored
- * [quad][q][super-step s][row i] (one float per lane: the MFMA of super-step s broadcasts block s
- * of its class, cbsz = 2 / abid = s).  Limits: sgp_spmm_pipe_max_union() staged rows
- * per tile, sgp_spmm_pipe_max_quads() quads per tile. */
-int sgp_spmm_pipe_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
-                      const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
-                      const int32_t* rowmap,
-                      int32_t n_tiles, int32_t max_union, int32_t max_tile_quads,
-                      const float* X, int64_t x_row_stride, int64_t x_batch_stride,
-                      const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
-                      int32_t n_own,
-                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
-                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                      sgp_stream_t stream);
-int32_t sgp_spmm_pipe_max_union(void);
-int32_t sgp_spmm_pipe_max_quads(void);
-/* Launch shape of sgp_spmm_pipe_f32 (process-wide; a negative / zero argument keeps the setting):
- * persist 0 = one workgroup per (tile, 32-step chunk); 1 = one workgroup per CU, the workgroups of
- * an XCD walk (32 neighbouring tiles, unit_steps time steps) units together; 2 = 1 + a bounded
- * rendezvous of the XCD's workgroups at every unit start.  Results are identical in every mode. */
-int sgp_spmm_pipe_tune(int32_t persist, int32_t unit_steps);
-
-/* Register-resident form of sgp_spmm_pipe_f32: same plan arrays and arithmetic (bit-identical
- * results), but a group's weights and the per-lane LDS addresses of its staged rows are loaded
- * once per workgroup into VGPRs, so a super-step is one ds_read_b128 + 4 MFMAs with no VALU
- * address arithmetic and no stream reads from LDS (ranges longer than 20 super-steps continue from
- * an LDS copy of the stream).  Limits as for sgp_spmm_pipe_f32: sgp_spmm_res_max_union() staged
- * rows and sgp_spmm_res_max_quads() quads per tile.  sgp_spmm_res_tune(cfg): 0 = 16 waves x 1 group
- * per workgroup, 1 = 8 waves x 2 groups (process-wide). */
+/* Row-group kernel on the fp32 matrix cores, exact fp32 (lib/sgp_preprocessing.py:200-203, `x = adj @ x` per hop).
+ * Tiles of at most 64 rows and their distinct-column lists as above; every tile is cut into 16 groups of 4
+ * rows (slots 4g .. 4g+3 of the tile, see rowmap).  A group's sorted column union is dealt round-robin to 4
+ * classes q; super-step s handles the s-th column of every class with one v_mfma_f32_4x4x1_16b_f32 per
+ * feature.  The stream is stored 4 super-steps ("quad") at a time.  The tile's distinct-column list is cut
+ * at usplit[k] (a multiple of 4) into segment A (list positions < usplit[k]) and segment B; a group's quads
+ * are stored A-part first and never mix the segments: gptr[2 (16 k + g)] .. gptr[2 (16 k + g) + 1] = quads
+ * on segment A, .. gptr[2 (16 k + g) + 2] = quads on segment B.  Per time step the kernel refills one
+ * segment of the LDS stage by LDS-DMA (global_load_lds_dwordx4) while the matrix cores consume the other.
+ *   gw  [quad][q][super-step s][row i]  float  weight of row i for class q's column in super-step s of the
+ *                                        quad (0 = row lacks the column / padding); the MFMA of super-step s
+ *                                        broadcasts block s of its class (cbsz = 2 / abid = s)
+ *   gidx[quad][q][4]          int32   256 * index of that column in the tile's ucol list, i.e. the byte
+ *                                     offset of its staged row in LDS (0 = padding)
+ *   gsup[2 (16 k + g) + s]    int32   ceil(columns of that range / 4): the padding of a range's last quad is
+ *                                     skipped in units of one super-step
+ *   rowmap[64 * k + 4 g + i]  int32   output row of slot i of group g of tile k, -1 = empty (the host may
+ *                                     permute rows inside a tile so that the 4 rows of a group share columns)
+ * uptr / ucol list segment A first (padded to a multiple of 4 entries), then segment B.  A group's weights
+ * and the per-lane LDS addresses of its staged rows are loaded once per workgroup into VGPRs, so a super-step
+ * is one ds_read_b128 + 4 MFMAs with no VALU address arithmetic and no stream reads from LDS (ranges longer
+ * than the resident super-steps continue from an LDS copy of the stream).  Limits: sgp_spmm_res_max_union()
+ * staged rows and sgp_spmm_res_max_quads() quads per tile.  sgp_spmm_res_tune(cfg): 0 = 16 waves x 1 group
+ * per workgroup, 1 = 8 waves x 2 groups (process-wide).
+ * (Round 4 retired this kernel's predecessors sgp_spmm_mfma_f32 / sgp_spmm_pipe_f32 and the row-block form
+ * sgp_spmm_blk_f32 -- superseded on every measured workload; their sources are kept under tools/experiments/.) */
 int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
                      const int32_t* gptr, const int32_t* gsup, const int32_t* gidx, const float* gw,
                      const int32_t* rowmap,
@@ -226,15 +187,16 @@ int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride
  * by v_mfma_f32_16x16x32_f16: results agree with an fp32 evaluation to ~1e-7 of the input scale (measured
  * against fp64: closer than an fp32 fma chain), at 16x the fp32 matrix rate, which pays for dense 16 x 32
  * blocks of A and 256-row tiles (3.1 staged source rows per result row instead of 5.8).  Arrays:
- *   hdr[n_tiles][32]                         first row of each of the 8 waves, rows of each wave, staged rows U
+ *   hdr[n_tiles][32]                         [8:16] rows of each of the 8 waves, [16] staged rows U
+ *   rowid[n_tiles][8][32]                    result row of every slot (16 half + m) of every wave, -1 = empty
  *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
  *   afr[n_tiles][8][chunks][4][64][8] fp16   A fragments in lane order (2 * half + piece)
  *   adr[n_tiles][8][chunks][2][64]           per-lane plane byte address of the transpose reads
  * with chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0; no halo
  * source.  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
  * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */
-int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const void* afr, const int32_t* adr,
-                       int32_t n_tiles,
+int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
+                       const int32_t* adr, int32_t n_tiles,
                        const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
@@ -264,38 +226,6 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
                           sgp_stream_t stream);
 int32_t sgp_spmm_colblock_rows_cap(void);
 int32_t sgp_spmm_colblock_round_pad(void);
-
-/* Row-block form of the row-group product (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
- * sgp_amd/rowblock.py).  A workgroup of sgp_spmm_blk_waves() = 8 waves owns a tile of up to 128
- * rows; a wave owns FOUR 4-row groups, one per 16-lane class of v_mfma_f32_4x4x1_16b_f32, and
- * every class walks its own column list, so a lane's accumulators hold finished sums (no fold
- * across lanes).  Staging as in sgp_spmm_pipe_f32 (two LDS-DMA segments per step).  Arrays:
- *   uptr[n_tiles + 1], ucol[]      staged source rows of a tile, segment A first (padded to 4 rows)
- *   usplit[n_tiles]                rows of segment A
- *   wptr[2 * waves * n_tiles + 1]  first super-step of (tile, wave, segment) in soff / sw
- *                                  (multiples of 4), nsteps[] = its length (longest class)
- *   soff[n_super][4]               LDS byte offset (staged row * 256) of class q's source row
- *   sw[n_super / 4][64]            weights, one float per lane and 4 super-steps: lane
- *                                  16 q + 4 b + i = row i of class q in super-step 4 p + b
- *   rowmap[16 * waves * n_tiles]   result row of (tile, wave, class, i), -1 = none
- * max_union = staged rows of the largest tile (<= sgp_spmm_blk_max_union()).  X / X_halo / Y as
- * in sgp_spmm_tiled_f32.  Arithmetic: exact fp32 FMA chain per (row, feature) in the order of the
- * class's staged rows. */
-int sgp_spmm_blk_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* usplit,
-                     const int32_t* wptr, const int32_t* nsteps, const int32_t* soff, const float* sw,
-                     const int32_t* rowmap,
-                     int32_t n_tiles, int32_t waves, int32_t max_union,
-                     const float* X, int64_t x_row_stride, int64_t x_batch_stride,
-                     const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride,
-                     int32_t n_own,
-                     float* Y, int64_t y_row_stride, int64_t y_batch_stride,
-                     int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream);
-int32_t sgp_spmm_blk_max_union(void);
-int32_t sgp_spmm_blk_waves(void);
-/* Register split of the kernel (process-wide): 0 = 72 resident super-steps per segment and an
- * operand ring 4 deep, 1 = 64 / 6, 2 = 56 / 8.  Results do not depend on it. */
-int sgp_spmm_blk_tune(int32_t cfg);
 
 /* Limits of the tiled kernel: largest per-tile distinct-column count it can stage for
  * `feat` (0 = feat unsupported; feat must be a multiple of 64), largest tile height and
@@ -389,7 +319,7 @@ int sgp_reservoir_fused_sums_f32(const float* x, int64_t x_row_stride, int64_t x
  *                        the [T, N, L*R] embedding).  z, p, h_in, h_out: contiguous [N, R].
  */
 int64_t sgp_gesn_workspace_bytes(int32_t N, int32_t R, int32_t L);
-/* sgp_gesn_tune(persistent): 1 (default, also SGP_GESN_PERSISTENT=1) lets sgp_gesn_f32 run the
+/* sgp_gesn_tune(persistent): 1 (default, also SGP_TUNE=gesn_persistent=1) lets sgp_gesn_f32 run the
  * sequence in ONE cooperative launch per 256 steps when the shape allows it (R % 16 == 0, R <= 384,
  * L <= 8, the (layer, column group, row tile) items fit one workgroup per CU; csrc/gesn_persist.hip:
  * layers as a wavefront, weights in registers, one grid barrier per step); 0 = always two launches

@@ -1,6 +1,7 @@
 // ABI bookkeeping, error reporting and HIP-event timing helpers.
 #include "common.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace sgp {
 static thread_local char g_err[512] = "";
@@ -11,6 +12,17 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+long tune(const char* key, long dflt) {
+    const char* e = getenv("SGP_TUNE");
+    if (!e) return dflt;
+    const size_t kl = strlen(key);
+    for (const char* p = e; *p;) {
+        while (*p == ',' || *p == ' ') ++p;
+        if (!strncmp(p, key, kl) && p[kl] == '=') return strtol(p + kl + 1, nullptr, 10);
+        while (*p && *p != ',') ++p;
+    }
+    return dflt;
 }
 }  // namespace sgp
 

@@ -17,6 +17,9 @@ inline int check_launch(const char* what) {
     return 0;
 }
 
+// SGP_TUNE="key=value,key=value": the one debug / tuning hook (keys: sgp_amd/tune.py); default when absent
+long tune(const char* key, long dflt);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -385,9 +385,9 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
 
 int ksb_of(int R) { const int k = ((R >> 4) + 3) / 4; return k <= 2 ? 2 : (k <= 4 ? 4 : 6); }
 
-int g_mode = -1;                           // -1: read SGP_GESN_PERSISTENT once; 0 off; 1 on
+int g_mode = -1;                           // -1: read SGP_TUNE=gesn_persistent=.. once; 0 off; 1 on
 int mode() {
-    if (g_mode < 0) { const char* e = getenv("SGP_GESN_PERSISTENT"); g_mode = e ? (atoi(e) != 0) : 1; }
+    if (g_mode < 0) g_mode = sgp::tune("gesn_persistent", 1) != 0;
     return g_mode;
 }
 
@@ -461,7 +461,7 @@ int run_chunk(const int32_t* rowptr, const int32_t* col, const float* val, const
         a.om[l] = l < L ? (float)(1.0 - alpha[l]) : 0.f;
     }
     a.act = act; a.tc = tc; a.N = N; a.R = R; a.L = L;
-    { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SGP_GESN_DBG"); dbg = e ? atoi(e) : 0; } a.dbg = dbg; }
+    { static int dbg = -1; if (dbg < 0) dbg = (int)sgp::tune("gesn_dbg", 0); a.dbg = dbg; }
     return launch(a, n_blocks, lds, stream);
 }
 

@@ -771,12 +771,8 @@ int launch_layer(ResArgs a, hipStream_t s) {
 
 template <int JT, int NKX> int launch_stream_ool(const ResArgs& a, hipStream_t s);   // reservoir_stream.hip
 
-// experiment knobs (read once): SGP_RES_SPLITJ_MAX = largest tile count served by the split-J kernel
-// alone, SGP_RES_TAIL = 0 disables the exact deal + split-J tail of large problems
-inline int res_env(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
+// experiment knobs (SGP_TUNE, read once): res_splitj_max = largest tile count served by the split-J kernel
+// alone, res_tail = 0 disables the exact deal + split-J tail of large problems
 
 template <int JT, int NKX>
 int launch_splitj(const ResArgs& a, int n_tiles, hipStream_t s) {
@@ -800,7 +796,7 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
         // up to 2 workgroups per CU.  (Three per CU -- 513-768 tiles in one round, which the 3-deep ring
         // makes possible at F = R = 64 -- measured slower than one single-tile wave per SIMD: N = 10 000,
         // 1.53 vs 1.37 ms per 512 steps; SGP_RES_SPLITJ_MAX=768 selects it.)
-        static const int splitj_max = res_env("SGP_RES_SPLITJ_MAX", 512);
+        static const int splitj_max = (int)sgp::tune("res_splitj_max", 512);
         if (n_tiles <= splitj_max)
             return launch_splitj<JT, NKX>(a, n_tiles, s);
     }
@@ -809,7 +805,7 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
         // tiles that are left as a split-J tail: 4 SIMDs share a tile there, a workgroup steps through
         // T in ~0.7 us per step -- a fraction of the per + 1'th tile that the busiest SIMDs would
         // otherwise carry while the others idle (N = 100k: 6250 tiles = 6.1 per SIMD, 7 on the busiest).
-        static const int tail = res_env("SGP_RES_TAIL", 1);
+        static const int tail = (int)sgp::tune("res_tail", 1);
         const int per = n_tiles / 1024, left = n_tiles - per * 1024;
         if (tail && per >= 1 && per <= 8 && left <= 512) {
             ResArgs m = a;

@@ -525,7 +525,7 @@ int sgp_reservoir_fused_sums_f32(const float* x, int64_t xrs, int64_t xss,
         a.oma[l] = (float)(1.0 - al);              // `(1 - alpha) * h` (reservoir.py:80)
     }
     a.act = act; a.T = T; a.N = N; a.F = F; a.R = R; a.L = L; a.ntw = 1; a.n_tiles = 0;
-    { const char* e = getenv("SGP_STACK_DEBUG"); a.debug = e ? atoi(e) : 0; }   // bit 0: skip the result stores (timing ablation)
+    a.debug = (int)sgp::tune("stack_debug", 0);   // bit 0: skip the result stores (timing ablation)
     switch (jt) {
         case 1: return launch_stack_nkx<1>(a, nkx, s);
         case 2: return launch_stack_nkx<2>(a, nkx, s);

@@ -569,12 +569,12 @@ unsigned* mix_dbg_buffer() {
 
 int g_mix_mode = -1;
 int mix_mode() {
-    if (g_mix_mode < 0) { const char* e = getenv("SGP_MIX_MODE"); g_mix_mode = e ? atoi(e) : 6; }
+    if (g_mix_mode < 0) g_mix_mode = (int)sgp::tune("mix_mode", 6);
     return g_mix_mode;
 }
 int mix_chunk_cap() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("SGP_SPMM_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }
+    if (v < 0) { v = (int)sgp::tune("spmm_chunk", 32); if (v < 1) v = 32; }
     return v;
 }
 
@@ -598,7 +598,7 @@ int launch_mix(const MixArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(a.n_tiles * a.n_tchunks), a.feat / 64);
 #ifdef SGP_ABLATION
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = (int)sgp::tune("abl", 0);
 #define SGP_ABL(V)                                                                                 \
     if (abl == V) {                                                                                \
         auto k4 = spmm_mix<HALO, SH, DH, D, DD, ILV, V>;                                                \

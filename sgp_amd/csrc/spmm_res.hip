@@ -425,12 +425,12 @@ unsigned* res_dbg_buffer() {
 
 int g_res_cfg = -1;
 int res_cfg() {                                            // 0: 16 waves x 1 group, 1: 8 waves x 2 groups
-    if (g_res_cfg < 0) { const char* e = getenv("SGP_SPMM_RES_CFG"); g_res_cfg = e ? atoi(e) : 0; }
+    if (g_res_cfg < 0) g_res_cfg = (int)sgp::tune("res_cfg", 0);
     return g_res_cfg;
 }
 int res_chunk_cap() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("SGP_SPMM_CHUNK"); v = e ? atoi(e) : 32; if (v < 1) v = 32; }
+    if (v < 0) { v = (int)sgp::tune("spmm_chunk", 32); if (v < 1) v = 32; }
     return v;
 }
 
@@ -440,7 +440,7 @@ int launch_res(const ResArgs& a, hipStream_t s) {
     dim3 grid((unsigned)(a.n_tiles * a.n_tchunks), a.feat / 64);
 #ifdef SGP_ABLATION
     static int abl = -1;
-    if (abl < 0) { const char* e = getenv("SGP_PIPE_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl < 0) abl = (int)sgp::tune("abl", 0);
 #define SGP_ABL(V)                                                                                 \
     if (abl == V) {                                                                                \
         auto k4 = spmm_res<HALO, NW, G, D, PASSES, V>;                                             \

@@ -40,17 +40,17 @@ constexpr int SMAX = 768;                    // staged rows per tile
 constexpr int NLD = SMAX / (16 * NW);        // 6 LDS-DMA instructions per wave and unit (16 rows each)
 constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
 constexpr int NBUF = 3;                      // landing | being converted | being multiplied
-constexpr int HDR = 32;                      // ints per tile header: row0[8], cnt[8], U, pad
+constexpr int HDR = 32;                      // ints per tile header: [8:16] rows of every wave, [16] staged rows U
 
 struct SplitArgs {
-    const int* hdr; const int* ucol; const h8* afr; const int* adr;
+    const int* hdr; const int* rowid; const int* ucol; const h8* afr; const int* adr;
     int n_tiles, tiles_per_xcd;
     const float* X; long long xrs, xbs;
     float* Y; long long yrs, ybs;
     int batch, nslice, t_chunk;
     float x_scale, inv_scale;
     unsigned long long* dbg;                 // mode 256: per-wave s_memtime stamps of workgroup 0
-    int mode;                                // ablations (SGP_SPLIT_ABL): 1 no loads, 2 no MFMAs, 4 no stores, 8 no conversion, 16 all tiles of an XCD stage the same rows (upper bound of L2 sharing), 32 unpaired stores
+    int mode;                                // ablations (SGP_TUNE=split_abl=..): 1 no loads, 2 no MFMAs, 4 no stores, 8 no conversion, 16 all tiles of an XCD stage the same rows (upper bound of L2 sharing), 32 unpaired stores
 };
 
 // B operand of one chunk: four transpose reads (hi / lo piece x rows k = 0..3 / 4..7 of every lane group).  Issued
@@ -114,8 +114,6 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int* hd = a.hdr + (size_t)tile * HDR;
-    const int row0 = __builtin_amdgcn_readfirstlane(hd[wave]);
-    const int cnt = __builtin_amdgcn_readfirstlane(hd[NW + wave]);
     const int src_tile = (a.mode & 16) ? xcd * a.tiles_per_xcd : tile;   // 16: every tile of an XCD stages the same rows
     const int nU = __builtin_amdgcn_readfirstlane(a.hdr[(size_t)src_tile * HDR + 2 * NW]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -188,8 +186,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         const float rc = swap2(b1 ? a0 : a2), rd = swap2(b1 ? a1 : a3);
         r[0] = b1 ? rc : a0; r[1] = b1 ? rd : a1; r[2] = b1 ? a2 : rc; r[3] = b1 ? a3 : rd;
     };
+    // after the transpose this lane stores row slots my_slot (half 0) and 16 + my_slot (half 1); -1 = empty slot
     const int my_slot = 4 * (lane >> 4) + (lane & 3);
-    const long long yoff = (long long)(row0 + my_slot) * a.yrs + 4 * ((lane >> 2) & 3);
+    const int* rid = a.rowid + (size_t)(tile * NW + wave) * 32;
+    const int row_a = rid[my_slot], row_b = rid[16 + my_slot];
+    const long long yoff_a = (long long)row_a * a.yrs + 4 * ((lane >> 2) & 3);
+    const long long yoff_b = (long long)row_b * a.yrs + 4 * ((lane >> 2) & 3);
 
     const int n_units = (t_end - t_begin) * a.nslice;
     // DMA cursor (two units ahead of the multiply) and multiply cursor
@@ -260,13 +262,13 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
             if (!(sl & 1) && sl + 1 < a.nslice && !(a.mode & 32)) {
                 h0 = r0; h1 = r1;
             } else {
-                float* yb = a.Y + (long long)t * a.ybs + sl * 16 + yoff;
+                float* yb = a.Y + (long long)t * a.ybs + sl * 16;
                 if ((sl & 1) && !(a.mode & 32)) {
-                    if (my_slot < cnt) { *(f32x4*)(yb - 16) = h0; *(f32x4*)yb = r0; }
-                    if (16 + my_slot < cnt) { *(f32x4*)(yb + 16 * a.yrs - 16) = h1; *(f32x4*)(yb + 16 * a.yrs) = r1; }
+                    if (row_a >= 0) { *(f32x4*)(yb + yoff_a - 16) = h0; *(f32x4*)(yb + yoff_a) = r0; }
+                    if (row_b >= 0) { *(f32x4*)(yb + yoff_b - 16) = h1; *(f32x4*)(yb + yoff_b) = r1; }
                 } else {
-                    if (my_slot < cnt) *(f32x4*)yb = r0;
-                    if (16 + my_slot < cnt) *(f32x4*)(yb + 16 * a.yrs) = r1;
+                    if (row_a >= 0) *(f32x4*)(yb + yoff_a) = r0;
+                    if (row_b >= 0) *(f32x4*)(yb + yoff_b) = r1;
                 }
             }
         }
@@ -284,7 +286,8 @@ extern "C" int32_t sgp_spmm_split_chunks(void) { return NCH; }
 extern "C" int32_t sgp_spmm_split_max_union(void) { return SMAX; }
 extern "C" int32_t sgp_spmm_split_waves(void) { return NW; }
 
-extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const void* afr, const int32_t* adr,
+extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
+                                  const int32_t* adr,
                                   int32_t n_tiles,
                                   const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                                   float* Y, int64_t y_row_stride, int64_t y_batch_stride,
@@ -292,7 +295,7 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const
                                   float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream) {
     SGP_REQUIRE(n_tiles >= 0 && batch >= 0 && n_rows >= 0 && n_cols >= 0, "spmm_split: negative size");
     if (n_tiles == 0 || batch == 0 || n_rows == 0) return 0;
-    SGP_REQUIRE(hdr && ucol && afr && adr && X && Y, "spmm_split: null pointer");
+    SGP_REQUIRE(hdr && rowid && ucol && afr && adr && X && Y, "spmm_split: null pointer");
     SGP_REQUIRE(feat > 0 && feat % 16 == 0, "spmm_split: feat = %d is not a multiple of 16", feat);
     SGP_REQUIRE(sgp::aligned16(X) && x_row_stride % 4 == 0 && x_batch_stride % 4 == 0 &&
                 sgp::aligned16(Y) && y_row_stride % 4 == 0 && y_batch_stride % 4 == 0,
@@ -301,7 +304,7 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const
                 "spmm_split: source rows beyond 32-bit byte offsets");
     SGP_REQUIRE(x_scale > 0.f && w_scale > 0.f, "spmm_split: scales must be positive");
     SplitArgs a;
-    a.hdr = hdr; a.ucol = ucol; a.afr = (const h8*)afr; a.adr = adr;
+    a.hdr = hdr; a.rowid = rowid; a.ucol = ucol; a.afr = (const h8*)afr; a.adr = adr;
     a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
     a.X = X; a.xrs = x_row_stride; a.xbs = x_batch_stride;
     a.Y = Y; a.yrs = y_row_stride; a.ybs = y_batch_stride;
@@ -313,7 +316,7 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* ucol, const
     }
     a.t_chunk = t_chunk;
     a.x_scale = x_scale; a.inv_scale = 1.f / (x_scale * w_scale);
-    static const int abl = getenv("SGP_SPLIT_ABL") ? atoi(getenv("SGP_SPLIT_ABL")) : 0;
+    static const int abl = (int)sgp::tune("split_abl", 0);
     a.mode = abl;
     a.dbg = nullptr;
     if (abl & 256) { if (hipMalloc(&a.dbg, 8 * NW * 8 * 8) != hipSuccess) return sgp::fail(SGP_EINVAL, "dbg alloc"); (void)hipMemset(a.dbg, 0, 8 * NW * 8 * 8); }

@@ -17,6 +17,8 @@ from typing import Optional
 
 import os
 
+from . import tune
+
 import numpy as np
 import torch
 
@@ -197,31 +199,6 @@ class ShiftOperator:
             return self._plans[(key, "std")]
         return self._plans[key]
 
-    def block_plan(self, feat, device):
-        """Row-block plan (``sgp_amd.rowblock``, kernel ``sgp_spmm_blk_f32``) or None: needs
-        feature widths that are multiples of 64 and a graph whose 4-row groups share most of their
-        columns (k-NN-like); reuses the locality order of ``tile_plan`` for scrambled numberings."""
-        key = ("blk", feat % 64 == 0, str(device))
-        if key not in self._plans:
-            plan = None
-            base = self.tile_plan(feat, device, tall=False)
-            if base is not None and base.gw is not None and base.group_fill >= 0.5 and \
-                    self.num_nodes >= 256:
-                from . import hip, rowblock
-                lib = hip.load()
-                order = None
-                if base.reordered:
-                    order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
-                plan = rowblock.build_rowblock_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
-                                                    self.num_nodes, lib.sgp_spmm_blk_max_union(),
-                                                    lib.sgp_spmm_blk_waves(), order=order)
-                if plan is not None and (plan.fill < 0.5 or plan.tile_rows < 64):
-                    plan = None
-                if plan is not None:
-                    plan = plan.to(device)
-            self._plans[key] = plan
-        return self._plans[key]
-
     def colblock_plan(self, feat, device):
         """Column-blocked plan (``sgp_amd.colblock``, kernel ``sgp_spmm_colblock_f32``) for graphs
         without locality, or None (feature widths that are not multiples of 64, >= 2^23 columns)."""
@@ -235,7 +212,7 @@ class ShiftOperator:
                                                     self.num_nodes, self.num_cols, feat,
                                                     rows_cap=lib.sgp_spmm_colblock_rows_cap(),
                                                     round_pad=lib.sgp_spmm_colblock_round_pad(),
-                                                    l2_bytes=float(os.environ.get("SGP_COLBLOCK_L2_MB", "2.5")) * 2 ** 20)
+                                                    l2_bytes=tune.get("colblock_l2_mb", 2.5, float) * 2 ** 20)
                 if plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
@@ -245,7 +222,7 @@ class ShiftOperator:
         """Mixed dense / sparse plan (``sgp_amd.mixplan``, kernel ``sgp_spmm_mix_f32``) on the tiles and
         row groups of the 64-row plan, or None: needs feature widths that are multiples of 64, a
         two-phase stream, and blocks of 16 rows that share enough columns for the dense form to pay
-        (k-NN-like graphs; ``SGP_MIX_MIN_SHARE``, default 0.25 of the (group, column) pairs)."""
+        (k-NN-like graphs; ``SGP_TUNE=mix_min_share=..``, default 0.25 of the (group, column) pairs)."""
         key = ("mix", feat % 64 == 0, str(device), bool(strict))
         if key not in self._plans:
             plan = None
@@ -258,9 +235,9 @@ class ShiftOperator:
                     order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
                 plan = mixplan.build_mix_plan(
                     self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, base,
-                    thr=int(os.environ.get("SGP_MIX_THR", "4")),
+                    thr=tune.get("mix_thr", 4, int),
                     dh=lib.sgp_spmm_mix_max_dense(int(self.num_cols > self.num_nodes)), order=order)
-                min_share = float(os.environ.get("SGP_MIX_MIN_SHARE", "0.25")) if strict else -1.0
+                min_share = tune.get("mix_min_share", 0.25, float) if strict else -1.0
                 if plan is not None and (plan.dense_share < min_share
                                          or plan.max_union > lib.sgp_spmm_mix_max_union()):
                     plan = None
@@ -279,11 +256,20 @@ class ShiftOperator:
             if self.num_cols == self.num_nodes and self.nnz() > 0:
                 from . import hip, splitplan
                 lib = hip.load()
-                plan = splitplan.build_split_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
-                                                  self.num_nodes, self.num_cols,
-                                                  waves=lib.sgp_spmm_split_waves(),
-                                                  chunks=lib.sgp_spmm_split_chunks(),
-                                                  max_union=lib.sgp_spmm_split_max_union())
+                lim = dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
+                           max_union=lib.sgp_spmm_split_max_union())
+                args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
+                plan = splitplan.build_split_plan(*args, **lim)
+                # numberings without locality (32 consecutive rows share no columns): deal the rows in a
+                # locality order of the graph itself, as the tile plans do
+                if plan is not None and plan.stats["rows_per_wave"] < 24 and self.num_nodes >= 2048:
+                    alt = splitplan.build_split_plan(*args, order=locality_order(
+                        self.rowptr.numpy(), self.col.numpy(), self.num_nodes), **lim)
+                    if alt is not None and alt.stats["staged_per_row"] < plan.stats["staged_per_row"]:
+                        plan = alt
+                # a plan that stages many rows per result row (no locality at all) loses to the other kernels
+                if plan is not None and (plan.stats["rows_per_wave"] < 12 or plan.stats["staged_per_row"] > 8):
+                    plan = None
                 if plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
@@ -292,7 +278,7 @@ class ShiftOperator:
     def split_eligible(self, x, y, halo=None):
         """Whether ``propagate`` would pick the split-fp16 hop on its own for these operands (callers that
         know a bound on |x| pass it; others let ``propagate`` measure one)."""
-        return (halo is None and os.environ.get("SGP_HOP", "split") == "split"
+        return (halo is None and tune.get("hop", "split") == "split"
                 and self.num_cols == self.num_nodes and x.is_cuda
                 and x.shape[2] % 16 == 0 and x.shape[1] * max(x.stride(1), 1) < 2 ** 29
                 and x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
@@ -328,7 +314,10 @@ class ShiftOperator:
                              f"{self.num_cols} columns, {y.shape[1]} result rows for {self.num_nodes}")
         if halo is not None and (halo.shape[0] != x.shape[0] or halo.shape[2] != x.shape[2]):
             raise ValueError("halo batch / feature size differs from x")
-        plan = None if force in ("csr", "colblock") else self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
+        if force not in (None, "csr", "tiled", "res", "mix", "colblock", "split"):
+            raise ValueError(f"unknown kernel {force!r} (csr, tiled, res, mix, colblock, split)")
+        plan = None if force in ("csr", "colblock", "split") else \
+            self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,
         # far * xhrs, n_rows * yrs < 2^30); beyond that -- e.g. a [rows, T, D] halo receive buffer of a
         # long time chunk, whose row stride is T * D -- the generic CSR kernel (64-bit addressing) serves
@@ -336,9 +325,8 @@ class ShiftOperator:
             not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30)
         if not fits32 and force in (None, "csr"):
             plan = None
-        halo_fits = fits32
-        # split-fp16 hop: first choice on one GPU where the plan exists; results agree with the
-        # exact-fp32 kernels to ~1e-7 of the operand scale.  SGP_HOP=exact keeps the fp32 matrix-core kernels.
+        # 1. split-fp16 hop: first choice on one GPU where the plan exists; results agree with the
+        # exact-fp32 kernels to ~1e-7 of the operand scale.  SGP_TUNE=hop=exact keeps the fp32 matrix-core kernels.
         if force == "split" or (force is None and self.split_eligible(x, y, halo)):
             splan = self.split_plan(x.device) if halo is None and x.shape[2] % 16 == 0 else None
             if splan is not None:
@@ -352,69 +340,43 @@ class ShiftOperator:
                     return y
             if force == "split":
                 raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")
-        # mixed dense (16x16x4) / sparse (4x4x1) kernel: first choice where the planner finds enough shared
-        # columns (k-NN-like graphs; measured 1-2 % faster than spmm_res on the 100-NN target graph);
-        # SGP_SPMM_DEFAULT=res switches it off
-        if force is None and plan is not None and halo_fits and os.environ.get("SGP_SPMM_DEFAULT", "mix") == "mix":
-            mplan = self.mix_plan(x.shape[2], x.device)
-            if mplan is not None:
-                self.last_kernel = "spmm_mix"
-                hip.spmm_mix(mplan, x, y, halo, self.num_nodes)
-                return y
-        # row-block kernel: on request only (measured on the target graph: better compute, 10.3 vs
-        # 10.7 ms per 512 steps without staging, but its 128-row tiles halve the number of time
-        # steps of an XCD's working set that fit the L2 -- 14.9 vs 12.8 ms with staging)
-        if force == "blk" and plan is not None and \
-                not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30):
-            bplan = self.block_plan(x.shape[2], x.device)
-            if bplan is not None:
-                self.last_kernel = "spmm_blk"
-                hip.spmm_blk(bplan, x, y, halo, self.num_nodes)
-                return y
-        if force == "blk":
-            raise NotImplementedError("no row-block plan for this graph / feature width")
-        if force == "mix" and plan is not None and \
-                not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30):
-            mplan = self.mix_plan(x.shape[2], x.device, strict=False)
+            plan = self.tile_plan(x.shape[2], x.device, tall=True) if fits32 else None
+        # 2. exact fp32 on the matrix cores: the mixed dense (16x16x4) / sparse (4x4x1) kernel where the planner
+        # finds enough shared columns (k-NN-like graphs), else the register-resident row-group kernel
+        if force in (None, "mix") and plan is not None and fits32 and \
+                (force == "mix" or tune.get("exact", "mix") == "mix"):
+            mplan = self.mix_plan(x.shape[2], x.device, strict=force is None)
             if mplan is not None:
                 self.last_kernel = "spmm_mix"
                 hip.spmm_mix(mplan, x, y, halo, self.num_nodes)
                 return y
         if force == "mix":
             raise NotImplementedError("no mixed dense / sparse plan for this graph / feature width")
-        if force in ("tiled", "mfma", "pipe", "res") and plan is None:
+        if force in ("tiled", "res") and plan is None:
             raise NotImplementedError("no tile plan for this graph / feature width")
-        if force == "mfma" and (plan is None or plan.gw is None):
-            raise NotImplementedError("no row-group stream for this plan")
-        # matrix-core row groups pay off when 4-row groups share most columns (k-NN graphs)
-        use_mfma = plan is not None and plan.gw is not None and \
-            (force in ("mfma", "pipe", "res") or (force is None and plan.group_fill >= 0.5 and
-                                 plan.max_tile_quads <= hip.load().sgp_spmm_mfma_max_quads()))
-        # register-resident form first (bit-identical to spmm_pipe, faster), then spmm_pipe
-        use_res = use_mfma and plan.pipe is not None and force in (None, "res") and \
-            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_res_max_quads() and \
-            plan.pipe["max_union"] <= hip.load().sgp_spmm_res_max_union()
+        lib = hip.load()
+        use_res = plan is not None and plan.gw is not None and plan.pipe is not None and \
+            (force == "res" or (force is None and plan.group_fill >= 0.5)) and \
+            plan.pipe["max_tile_quads"] <= lib.sgp_spmm_res_max_quads() and \
+            plan.pipe["max_union"] <= lib.sgp_spmm_res_max_union()
         if force == "res" and not use_res:
-            raise NotImplementedError("no two-phase stream for this plan")
-        use_pipe = use_mfma and not use_res and plan.pipe is not None and force in (None, "pipe") and \
-            plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
-        if force == "pipe" and not use_pipe:
-            raise NotImplementedError("no two-phase stream for this plan")
-        self.last_kernel = "spmm_res" if use_res else "spmm_pipe" if use_pipe else "spmm_mfma" if use_mfma else (
-            "spmm_tiled" if plan is not None else "spmm_csr_rows")
-        if plan is not None and plan.reordered and not use_mfma:
+            raise NotImplementedError("no two-phase row-group stream for this plan")
+        if use_res:
+            self.last_kernel = "spmm_res"
+            hip.spmm_res(plan, x, y, halo, self.num_nodes)
+            return y
+        if plan is not None and plan.reordered:
             if force == "tiled":
                 raise NotImplementedError("a reordered plan serves the row-group kernels only")
             plan = None                       # generic CSR kernel
-            self.last_kernel = "spmm_csr_rows"
-        # no tile plan (no locality to stage): when a time step's source rows exceed an L2 and the rows
+        # 3. no tile plan (no locality to stage): when a time step's source rows exceed an L2 and the rows
         # are not nearly empty, the column-blocked kernel keeps the gathers inside the L2 (random 100-column
-        # rows at N = 100k: 3x the generic kernel); small or very sparse operators stay with CSR
+        # rows at N = 100k: 1.3x the generic kernel); small or very sparse operators stay with CSR
         if force == "colblock" or (force is None and plan is None and halo is None and fits32
                                    and x.shape[2] % 64 == 0 and x.shape[0] >= 4
                                    and self.num_cols * x.shape[2] * 4 > 3 * 2 ** 20
                                    and self.nnz() >= 16 * self.num_nodes
-                                   and os.environ.get("SGP_SPMM_COLBLOCK", "1") != "0"):
+                                   and tune.get("colblock", 1, int) != 0):
             cplan = self.colblock_plan(x.shape[2], x.device) if halo is None else None
             if cplan is not None:
                 self.last_kernel = "spmm_colblock"
@@ -422,15 +384,12 @@ class ShiftOperator:
                 return y
             if force == "colblock":
                 raise NotImplementedError("no column-blocked plan for this operator / feature width / halo")
-        if use_res:
-            hip.spmm_res(plan, x, y, halo, self.num_nodes)
-        elif use_pipe:
-            hip.spmm_pipe(plan, x, y, halo, self.num_nodes)
-        elif use_mfma:
-            hip.spmm_mfma(plan, x, y, halo, self.num_nodes)
-        elif plan is not None:
+        # 4. VALU form of the staged kernel (sparse graphs, tall tiles), else the generic CSR kernel
+        if plan is not None:
+            self.last_kernel = "spmm_tiled"
             hip.spmm_tiled(plan, x, y, halo, self.num_nodes)
         else:
+            self.last_kernel = "spmm_csr_rows"
             rowptr, col, val = self.device_csr(x.device)
             hip.spmm_csr(rowptr, col, val, x, y, halo, self.num_nodes)
         return y
@@ -1019,11 +978,11 @@ def build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows, max_row_
                              max_range_steps=ps["max_range_steps"],
                              phase_cost=ps["phase_cost"])
             if equalize is None:
-                equalize = os.environ.get("SGP_EQUAL_COST_TILES", "0") == "1"
+                equalize = tune.get("equal_cost_tiles", 0, int) == 1
             if equalize and trow_override is None and tr == 64 and n_tiles >= 512:
                 new_trow = equal_cost_tiles(rowptr, col, n_rows, trow, ps["phase_cost"], tr,
                                             min(max_union, 65535),
-                                            float(os.environ.get("SGP_EQUAL_COST_Q", "0.15")))
+                                            tune.get("equal_cost_q", 0.15, float))
                 if new_trow is not None and len(new_trow) - 1 <= 1.4 * n_tiles:
                     alt = build_tile_plan(rowptr, col, val, n_rows, max_union, max_tile_rows,
                                           max_row_edges, candidates=(tr,), cluster=cluster,

@@ -36,21 +36,6 @@ SIGNATURES = {
                                           c_p, c_i64, c_i64, c_i32,
                                           c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_mfma_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                         c_i32, c_i32, c_i32,
-                                         c_p, c_i64, c_i64,
-                                         c_p, c_i64, c_i64, c_i32,
-                                         c_p, c_i64, c_i64,
-                                         c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_pipe_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                         c_i32, c_i32, c_i32,
-                                         c_p, c_i64, c_i64,
-                                         c_p, c_i64, c_i64, c_i32,
-                                         c_p, c_i64, c_i64,
-                                         c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_pipe_max_union": (c_i32, []),
-    "sgp_spmm_pipe_max_quads": (c_i32, []),
-    "sgp_spmm_pipe_tune": (ctypes.c_int, [c_i32, c_i32]),
     "sgp_spmm_res_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                         c_i32, c_i32, c_i32,
                                         c_p, c_i64, c_i64,
@@ -69,17 +54,6 @@ SIGNATURES = {
                                         c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_spmm_mix_max_union": (c_i32, []),
     "sgp_spmm_mix_max_dense": (c_i32, [c_i32]),
-    "sgp_spmm_blk_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
-                                        c_i32, c_i32, c_i32,
-                                        c_p, c_i64, c_i64,
-                                        c_p, c_i64, c_i64, c_i32,
-                                        c_p, c_i64, c_i64,
-                                        c_i32, c_i32, c_i32, c_i32, c_p]),
-    "sgp_spmm_blk_max_union": (c_i32, []),
-    "sgp_spmm_blk_waves": (c_i32, []),
-    "sgp_spmm_blk_tune": (ctypes.c_int, [c_i32]),
-    "sgp_spmm_mfma_max_union": (c_i32, []),
-    "sgp_spmm_mfma_max_quads": (c_i32, []),
     "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
     "sgp_spmm_tiled_max_tile_rows": (c_i32, []),
     "sgp_spmm_tiled_max_row_edges": (c_i32, []),
@@ -134,7 +108,7 @@ SIGNATURES = {
     "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                     c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_abs_max_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p, c_p]),
-    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p]),
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
@@ -291,48 +265,6 @@ def spmm_tiled(plan, x, y, halo=None, n_own=None):
 
 
 @_on_device
-def spmm_mfma(plan, x, y, halo=None, n_own=None):
-    """Row-group product on the matrix cores (v_mfma_f32_4x4x1_16b_f32)."""
-    lib = require_gpu()
-    xp, xrs, xbs = _view3(x, "x")
-    yp, yrs, ybs = _view3(y, "y")
-    if halo is not None:
-        hp, hrs, hbs = _view3(halo, "halo")
-        n_own = x.shape[1] if n_own is None else n_own
-    else:
-        hp, hrs, hbs, n_own = None, 0, 0, 0
-    _check(lib.sgp_spmm_mfma_f32(
-        plan.trow.data_ptr(), plan.uptr.data_ptr(), plan.ucol.data_ptr(),
-        plan.gptr.data_ptr(), plan.gidx.data_ptr(), plan.gw.data_ptr(), plan.rowmap.data_ptr(),
-        plan.n_tiles, plan.max_union, plan.max_tile_quads,
-        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
-        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mfma_f32")
-
-
-@_on_device
-def spmm_pipe(plan, x, y, halo=None, n_own=None):
-    """Two-phase pipelined row-group product (LDS-DMA staging, v_mfma_f32_4x4x1_16b_f32)."""
-    lib = require_gpu()
-    xp, xrs, xbs = _view3(x, "x")
-    yp, yrs, ybs = _view3(y, "y")
-    if halo is not None:
-        hp, hrs, hbs = _view3(halo, "halo")
-        n_own = x.shape[1] if n_own is None else n_own
-    else:
-        hp, hrs, hbs, n_own = None, 0, 0, 0
-    ps = plan.pipe
-    _check(lib.sgp_spmm_pipe_f32(
-        ps["uptr"].data_ptr(), ps["ucol"].data_ptr(), ps["usplit"].data_ptr(),
-        ps["gptr"].data_ptr(), ps["gsup"].data_ptr(), ps["gidx"].data_ptr(), ps["gw"].data_ptr(),
-        ps["rowmap"].data_ptr(),
-        plan.n_tiles, ps["max_union"], ps["max_tile_quads"],
-        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
-        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_pipe_f32")
-
-
-@_on_device
 def spmm_res(plan, x, y, halo=None, n_own=None):
     """Register-resident two-phase row-group product (same plan and results as spmm_pipe)."""
     lib = require_gpu()
@@ -377,27 +309,6 @@ def spmm_mix(plan, x, y, halo=None, n_own=None):
 
 
 @_on_device
-def spmm_blk(plan, x, y, halo=None, n_own=None):
-    """Row-block product (plan: sgp_amd.rowblock.RowBlockPlan on the device of ``x``)."""
-    lib = require_gpu()
-    xp, xrs, xbs = _view3(x, "x")
-    yp, yrs, ybs = _view3(y, "y")
-    if halo is not None:
-        hp, hrs, hbs = _view3(halo, "halo")
-        n_own = x.shape[1] if n_own is None else n_own
-    else:
-        hp, hrs, hbs, n_own = None, 0, 0, 0
-    _check(lib.sgp_spmm_blk_f32(
-        plan.uptr.data_ptr(), plan.ucol.data_ptr(), plan.usplit.data_ptr(),
-        plan.wptr.data_ptr(), plan.nsteps.data_ptr(), plan.soff.data_ptr(), plan.sw.data_ptr(),
-        plan.rowmap.data_ptr(),
-        plan.n_tiles, plan.waves, plan.max_union,
-        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
-        plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_blk_f32")
-
-
-@_on_device
 def abs_max(x):
     """max |x| of a [B, N, D] view as a Python float (one device reduction + one 4-byte copy)."""
     lib = require_gpu()
@@ -421,7 +332,8 @@ def spmm_split(plan, x, y, x_bound, t_chunk=0):
         raise ValueError("spmm_split needs a finite positive bound on |x|")
     x_scale = 2.0 ** math.floor(math.log2(16384.0 / x_bound))
     _check(lib.sgp_spmm_split_f32(
-        plan.hdr.data_ptr(), plan.ucol.data_ptr(), plan.afr.data_ptr(), plan.adr.data_ptr(), plan.n_tiles,
+        plan.hdr.data_ptr(), plan.rowid.data_ptr(), plan.ucol.data_ptr(), plan.afr.data_ptr(), plan.adr.data_ptr(),
+        plan.n_tiles,
         xp, xrs, xbs, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2],
         x_scale, plan.w_scale, t_chunk, _stream(x)), "sgp_spmm_split_f32")
 
@@ -442,8 +354,7 @@ def spmm_colblock(plan, x, y):
 def tiled_limits(feat):
     """Plan limits that satisfy every LDS-staged kernel at once (one plan serves them all)."""
     lib = load()
-    return dict(max_union=min(lib.sgp_spmm_tiled_max_union(feat), lib.sgp_spmm_mfma_max_union(),
-                                 lib.sgp_spmm_pipe_max_union()),
+    return dict(max_union=min(lib.sgp_spmm_tiled_max_union(feat), lib.sgp_spmm_res_max_union()),
                 max_tile_rows=min(lib.sgp_spmm_tiled_max_tile_rows(), 64),
                 max_row_edges=lib.sgp_spmm_tiled_max_row_edges())
 

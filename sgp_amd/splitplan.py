@@ -5,7 +5,9 @@ Rows are dealt in order to WAVES of at most 32 rows whose entries touch at most 
 columns, waves to TILES of at most ``waves`` waves whose rows touch at most ``max_union`` distinct columns
 (the tile's staged rows).  Per tile the kernel reads
 
-* ``hdr[tile]``            32 ints: first row of every wave, rows of every wave, staged rows U
+* ``hdr[tile]``            32 ints: rows of every wave at [8:16], staged rows U at [16]
+* ``rowid[tile, w, slot]``  result row of slot ``16 half + m`` of wave w, -1 = empty slot (rows are dealt in the
+                           given numbering or, for numberings without locality, in ``order``)
 * ``ucol[tile, s]``        column (= source row) staged at position s, -1 beyond U
 * ``afr[tile, w, c, q]``   A fragments of ``v_mfma_f32_16x16x32_f16`` in lane order, q = 2 * half + piece:
                            lane ``m + 16 g``, element e = piece of ``a[row slot 16 half + m, column k = 8 g + e of
@@ -22,25 +24,26 @@ import torch
 
 
 class SplitPlan:
-    def __init__(self, hdr, ucol, afr, adr, n_tiles, n_rows, n_cols, w_scale, norm_inf, stats):
-        self.hdr, self.ucol, self.afr, self.adr = hdr, ucol, afr, adr
+    def __init__(self, hdr, rowid, ucol, afr, adr, n_tiles, n_rows, n_cols, w_scale, norm_inf, stats):
+        self.hdr, self.rowid, self.ucol, self.afr, self.adr = hdr, rowid, ucol, afr, adr
         self.n_tiles, self.n_rows, self.n_cols = n_tiles, n_rows, n_cols
         self.w_scale, self.norm_inf, self.stats = w_scale, norm_inf, stats
 
     def to(self, device):
-        return SplitPlan(self.hdr.to(device), self.ucol.to(device), self.afr.to(device), self.adr.to(device),
-                         self.n_tiles, self.n_rows, self.n_cols, self.w_scale, self.norm_inf, self.stats)
+        return SplitPlan(self.hdr.to(device), self.rowid.to(device), self.ucol.to(device), self.afr.to(device),
+                         self.adr.to(device), self.n_tiles, self.n_rows, self.n_cols, self.w_scale, self.norm_inf,
+                         self.stats)
 
 
-def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=32):
-    """Greedy deal in row order.  Returns (wave_of_row, slot_of_row, tile_of_wave, first_row, rows) or None
-    when a single row exceeds a wave's column budget."""
+def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=32, order=None):
+    """Greedy deal in row order (``order``: the sequence in which rows are taken).  Returns (wave_of_row,
+    slot_of_row, tile_of_wave, rows) or None when a single row exceeds a wave's column budget."""
     cap = 32 * chunks
     wmark = np.full(n_cols, -1, dtype=np.int64)
     tmark = np.full(n_cols, -1, dtype=np.int64)
     wave_of_row = np.empty(n_rows, dtype=np.int64)
     slot_of_row = np.empty(n_rows, dtype=np.int64)
-    tile_of_wave, first_row, rows = [], [], []
+    tile_of_wave, rows = [], []
     wave, tile = -1, -1
     w_rows = w_cols = t_cols = t_waves = 0
 
@@ -53,10 +56,10 @@ def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wa
         t_waves += 1
         w_rows = w_cols = 0
         tile_of_wave.append(tile)
-        first_row.append(r)
         rows.append(0)
 
-    for r in range(n_rows):
+    for r in (range(n_rows) if order is None else order):
+        r = int(r)
         c = np.unique(col[rowptr[r]:rowptr[r + 1]])
         if c.size > cap or c.size > max_union:
             return None
@@ -79,8 +82,7 @@ def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wa
         slot_of_row[r] = w_rows
         w_rows += 1
         rows[wave] = w_rows
-    return (wave_of_row, slot_of_row, np.asarray(tile_of_wave, dtype=np.int64),
-            np.asarray(first_row, dtype=np.int64), np.asarray(rows, dtype=np.int64))
+    return (wave_of_row, slot_of_row, np.asarray(tile_of_wave, dtype=np.int64), np.asarray(rows, dtype=np.int64))
 
 
 def split_fp16(v):
@@ -96,16 +98,19 @@ def split_fp16(v):
     return hi, lo
 
 
-def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768):
+def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768, order=None):
+    """``order``: optional permutation of the rows (a locality order of the graph): rows are dealt to waves in
+    that sequence while the plan keeps addressing rows and columns by their ORIGINAL ids, so no tensor is
+    ever permuted."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
     if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
         return None
-    deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union)
+    deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, order=order)
     if deal is None:
         return None
-    wave_of_row, slot_of_row, tile_of_wave, first_row, rows = deal
+    wave_of_row, slot_of_row, tile_of_wave, rows = deal
     n_waves = tile_of_wave.size
     n_tiles = int(tile_of_wave[-1]) + 1
     first_wave_of_tile = np.searchsorted(tile_of_wave, np.arange(n_tiles))
@@ -155,28 +160,29 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     afr[tile_of_wave, w_in_tile, :, 1::2] = lo
 
     hdr = np.zeros((n_tiles, 32), dtype=np.int32)
-    hdr[tile_of_wave, w_in_tile] = first_row
     hdr[tile_of_wave, waves + w_in_tile] = rows
+    rowid = np.full((n_tiles, waves, 32), -1, dtype=np.int32)
+    all_rows = np.arange(n_rows)
+    rowid[tile_of_wave[wave_of_row], w_in_tile[wave_of_row], slot_of_row] = all_rows
     hdr[:, 2 * waves] = union
     rowsum = np.zeros(n_rows, dtype=np.float64)
     np.add.at(rowsum, row_of_edge, np.abs(val.astype(np.float64)))
     stats = dict(tiles=n_tiles, waves=n_waves, rows_per_wave=float(rows.mean()),
                  rows_per_tile=float(n_rows / n_tiles), staged_per_row=float(union.sum() / n_rows),
                  chunk_fill=float(wkey.size / (n_waves * chunks * 32)), max_union=int(union.max()))
-    return SplitPlan(torch.from_numpy(hdr), torch.from_numpy(ucol), torch.from_numpy(afr), torch.from_numpy(adr),
+    return SplitPlan(torch.from_numpy(hdr), torch.from_numpy(rowid), torch.from_numpy(ucol), torch.from_numpy(afr), torch.from_numpy(adr),
                      n_tiles, n_rows, n_cols, w_scale, float(rowsum.max()), stats)
 
 
 def plan_matrix(plan, n_rows, n_cols):
     """Dense matrix a plan encodes (hi + lo pieces, unscaled): test helper."""
-    hdr, ucol = plan.hdr.numpy(), plan.ucol.numpy()
+    hdr, ucol, rowid = plan.hdr.numpy(), plan.ucol.numpy(), plan.rowid.numpy()
     afr, adr = plan.afr.numpy().astype(np.float64), plan.adr.numpy()
     waves, chunks = afr.shape[1], afr.shape[2]
     out = np.zeros((n_rows, n_cols))
     for t in range(plan.n_tiles):
         for w in range(waves):
-            row0, cnt = int(hdr[t, w]), int(hdr[t, waves + w])
-            if cnt == 0:
+            if int(hdr[t, waves + w]) == 0:
                 continue
             for c in range(chunks):
                 for lane in range(64):
@@ -190,5 +196,5 @@ def plan_matrix(plan, n_rows, n_cols):
                         for half in range(2):
                             v = afr[t, w, c, 2 * half, lane, e] + afr[t, w, c, 2 * half + 1, lane, e]
                             if v != 0.0:
-                                out[row0 + 16 * half + m, int(ucol[t, s])] += v / plan.w_scale
+                                out[int(rowid[t, w, 16 * half + m]), int(ucol[t, s])] += v / plan.w_scale
     return out

@@ -1,0 +1,45 @@
+"""The ONE debug / tuning hook of the package: the environment variable ``SGP_TUNE``, a comma-separated list
+of ``key=value`` pairs, read by the Python layer (here) and by ``libsgp_amd.so`` (``sgp::tune`` in
+``csrc/api.hip``).  Nothing in it changes results beyond the documented tolerance; production use needs none
+of it.  Keys:
+
+Python layer
+    hop=split|exact         hop kernel family on one GPU: split-fp16 (default) or the exact-fp32 kernels
+    exact=mix|res           first choice among the exact-fp32 matrix-core kernels (default mix)
+    mix_thr=4               a column goes through the dense 16x16x4 part when >= thr of a block's 4 groups use it
+    mix_min_share=0.25      least share of (group, column) pairs in the dense part for the mixed kernel to be chosen
+    colblock=1|0            column-blocked hop for graphs without locality (0: generic CSR kernel)
+    colblock_l2_mb=2.5      L2 budget of one column block
+    equal_cost_tiles=0|1, equal_cost_q=0.15   experiment: tiles cut for equal cost
+
+Library (integers)
+    spmm_chunk=32           time steps per workgroup of the staged exact kernels
+    spmm_variant=1          inner-loop variant of sgp_spmm_tiled_f32
+    mix_mode=6, res_cfg=0   launch shapes of sgp_spmm_mix_f32 / sgp_spmm_res_f32
+    abl=0                   ablation bits of res / mix (only in builds with -DSGP_ABLATION)
+    split_abl=0             ablation bits of sgp_spmm_split_f32 (1 no loads, 2 no MFMAs, 4 no stores, 8 no
+                            conversion, 16 shared rows per XCD, 32 unpaired stores, 64 always step 0,
+                            128 same phase order for all waves, 256 per-wave timeline of workgroup 0)
+    split_sync=1            rounds of an XCD's workgroups start together (persistent launch)
+    gesn_persistent=1, gesn_dbg=0, stack_debug=0, res_splitj_max, res_tail=1   reservoir / DynGESN experiments
+"""
+import os
+
+
+def _table():
+    out = {}
+    for item in os.environ.get("SGP_TUNE", "").split(","):
+        if "=" in item:
+            k, v = item.split("=", 1)
+            out[k.strip()] = v.strip()
+    return out
+
+
+def get(key, default=None, cast=str):
+    v = _table().get(key)
+    if v is None or v == "":
+        return default
+    try:
+        return cast(v)
+    except ValueError:
+        raise ValueError(f"SGP_TUNE: {key}={v!r} is not a valid {cast.__name__}") from None

@@ -130,7 +130,7 @@ if not torch.cuda.is_available():
             continue
         ps = plan.pipe
         common = (P(x), feat, n * feat, None, 0, 0, 0, P(y), feat, n * feat, plan.n_rows, n, batch, feat, None)
-        for fn in (lib.sgp_spmm_pipe_f32, lib.sgp_spmm_res_f32):
+        for fn in (lib.sgp_spmm_res_f32,):
             rc = fn(P(ps["uptr"]), P(ps["ucol"]), P(ps["usplit"]), P(ps["gptr"]), P(ps["gsup"]), P(ps["gidx"]),
                     P(ps["gw"]), P(ps["rowmap"]), plan.n_tiles, ps["max_union"], ps["max_tile_quads"], *common)
             assert isinstance(rc, int) and rc != 0          # no device: an error, not a crash
@@ -142,10 +142,10 @@ if not torch.cuda.is_available():
                                       mp.n_tiles, mp.max_union, mp.max_dense, *common)
             assert isinstance(rc, int) and rc != 0
             n_plans += 1
-        bp = op.block_plan(feat, cpu)
-        if bp is not None:
-            rc = lib.sgp_spmm_blk_f32(P(bp.uptr), P(bp.ucol), P(bp.usplit), P(bp.wptr), P(bp.nsteps), P(bp.soff),
-                                      P(bp.sw), P(bp.rowmap), bp.n_tiles, bp.waves, bp.max_union, *common)
+        sp = op.split_plan(cpu)
+        if sp is not None and feat %% 16 == 0:
+            rc = lib.sgp_spmm_split_f32(P(sp.hdr), P(sp.rowid), P(sp.ucol), P(sp.afr), P(sp.adr), sp.n_tiles, P(x), feat, n * feat,
+                                        P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, 1.0, sp.w_scale, 0, None)
             assert isinstance(rc, int) and rc != 0
             n_plans += 1
     # reservoir layer: every dispatch branch of the launch logic (split-J, exact deal + tail, even deal, stream)

@@ -73,7 +73,7 @@ def test_spmm_csr_strided_slots_in_place():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     buf = torch.randn(t, n, p * d, device="cuda")
     ref = buf.clone()
-    for force in ("csr", "tiled", "mfma", "pipe", "res", "mix"):
+    for force in ("csr", "tiled", "res", "mix"):
         out = ref.clone()
         for k in range(1, p):
             op.propagate(out[:, :, (k - 1) * d:k * d], out[:, :, k * d:(k + 1) * d], force=force)
@@ -91,7 +91,7 @@ def test_spmm_tiled_knn(n, k, feat):
     plan = op.tile_plan(feat, torch.device("cuda"))
     assert plan is not None
     x = torch.randn(5, n, feat)
-    for force in ("tiled", "mfma", "pipe", "res", "mix"):
+    for force in ("tiled", "res", "mix"):
         y = torch.full((5, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -121,7 +121,7 @@ def test_sparse_graphs_take_tall_tiles(n, e, feat, t):
     op.propagate(x.cuda(), y)
     assert op.last_kernel == "spmm_tiled"
     close(y, ref)
-    for force in ("csr", "mfma", "res", "tiled"):
+    for force in ("csr", "res", "tiled"):
         y2 = torch.full((t, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y2, force=force)
         close(y2, ref)
@@ -152,65 +152,18 @@ def test_spmm_tiled_ragged_rows_empty_rows_and_long_batch():
     op = graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n)
     assert op.tile_plan(feat, torch.device("cuda")) is not None
     x = torch.randn(t, n, feat)
-    for force in ("tiled", "mfma", "pipe", "res", "mix"):
+    for force in ("tiled", "res", "mix"):
         y = torch.full((t, n, feat), float("nan"), device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
         assert float(y[:, ::7].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n,k,feat,t", [(1500, 20, 64, 5), (1500, 100, 64, 5), (900, 33, 128, 3),
-                                        (3000, 50, 64, 40), (700, 20, 192, 2)])
-def test_spmm_row_block_kernel(n, k, feat, t):
-    """sgp_spmm_blk_f32 (128-row tiles, a wave walks four row groups in its four lane classes)
-    against the dense fp32 product; t = 40 spans two time chunks."""
-    torch.manual_seed(n + k)
-    ei, ew, _ = synthetic.knn_graph(n, k, seed=7)
-    op = graph.ShiftOperator.from_edges(ei, ew, n)
-    assert op.block_plan(feat, torch.device("cuda")) is not None
-    x = torch.randn(t, n, feat)
-    y = torch.full((t, n, feat), float("nan"), device="cuda")
-    op.propagate(x.cuda(), y, force="blk")
-    close(y, dense_ref(op, x))
-    y2 = torch.empty_like(y)
-    op.propagate(x.cuda(), y2, force="csr")
-    close(y, y2, rtol=1e-6, atol=1e-6)
-
-
-def test_spmm_row_block_ragged_rows_and_long_ranges():
-    """Empty rows, ragged degrees, and groups whose column lists exceed the register-resident
-    part of the stream (rows that mix two distant neighbourhoods -> the overflow path)."""
-    torch.manual_seed(6)
-    n, feat, t = 2048, 64, 35
-    deg = torch.randint(0, 60, (n,))
-    deg[::7] = 0
-    tgt = torch.repeat_interleave(torch.arange(n), deg)
-    src = (tgt + torch.randint(-40, 41, tgt.shape)).clamp(0, n - 1)
-    # every 5th row also references a window 150 rows away: long, poorly shared column lists
-    far = torch.arange(0, n, 5)
-    far_t = torch.repeat_interleave(far, 90)
-    far_s = (far_t + 150 + torch.randint(0, 120, far_t.shape)) % n
-    ei = torch.stack([torch.cat([src, far_s]), torch.cat([tgt, far_t])])
-    op = graph.ShiftOperator.from_edges(ei, torch.rand(ei.shape[1]) + .1, n)
-    # (its fill is below what ShiftOperator.block_plan accepts: plan and launch directly)
-    from sgp_amd import rowblock
-    lib = hip.load()
-    plan = rowblock.build_rowblock_plan(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), n,
-                                        lib.sgp_spmm_blk_max_union(), lib.sgp_spmm_blk_waves())
-    assert plan is not None and plan.max_steps > 72      # exercises the overflow path
-    x = torch.randn(t, n, feat)
-    y = torch.full((t, n, feat), float("nan"), device="cuda")
-    hip.spmm_blk(plan.to(torch.device("cuda")), x.cuda(), y)
-    close(y, dense_ref(op, x))
-    empty = (op.rowptr[1:] == op.rowptr[:-1]).nonzero().flatten()
-    assert empty.numel() > 0 and float(y[:, empty].abs().max()) == 0.0
-
-
 def test_spmm_traffic_graph_small_n_long_t():
     ei, ew = synthetic.sparse_traffic_graph(325, 2369, seed=2)
     op = graph.ShiftOperator.from_edges(ei, ew, 325)
     x = torch.randn(600, 325, 128)
-    for force in ("csr", "tiled", "mfma", "pipe", "res"):
+    for force in ("csr", "tiled", "res"):
         y = torch.empty(600, 325, 128, device="cuda")
         op.propagate(x.cuda(), y, force=force)
         close(y, dense_ref(op, x))
@@ -890,11 +843,9 @@ def test_scrambled_node_labels_take_the_fast_path():
     x = torch.randn(t, n, d)
     y = torch.full((t, n, d), float("nan"), device="cuda")
     op.propagate(x.cuda(), y)
-    assert op.last_kernel in ("spmm_res", "spmm_mix") and op.tile_plan(d, torch.device("cuda")).reordered
-    y3 = torch.empty_like(y)
-    op.propagate(x.cuda(), y3, force="blk")
-    assert op.block_plan(d, torch.device("cuda")).reordered
-    close(y3, dense_ref(op, x))
+    assert op.last_kernel in ("spmm_res", "spmm_mix", "spmm_split")
+    op.propagate(x.cuda(), y, force="mix")
+    assert op.tile_plan(d, torch.device("cuda"), tall=False).reordered
     close(y, dense_ref(op, x))
     y2 = torch.empty_like(y)
     op.propagate(x.cuda(), y2, force="csr")
@@ -917,7 +868,7 @@ def test_properties_at_scale():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc = (torch.empty_like(x1) for _ in range(3))
-    for force in ("mix", "blk", "res", "pipe", "mfma", "tiled", "csr"):
+    for force in ("mix", "res", "tiled", "csr"):
         op.propagate(x1, ya, force=force); op.propagate(x2, yb, force=force)
         op.propagate(2 * x1 - 3 * x2, yc, force=force)
         close(yc, 2 * ya - 3 * yb, rtol=1e-4, atol=1e-4, fro=1e-5)          # linearity
@@ -942,11 +893,13 @@ def test_properties_on_the_target_graph():
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     plan = op.tile_plan(d, torch.device("cuda"))
     assert plan is not None and plan.pipe is not None
-    assert plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_pipe_max_quads()
+    assert plan.pipe["max_tile_quads"] <= hip.load().sgp_spmm_res_max_quads()
     x1, x2 = torch.randn(t, n, d, device="cuda"), torch.randn(t, n, d, device="cuda")
     ya, yb, yc, yr = (torch.empty_like(x1) for _ in range(4))
-    op.propagate(x1, ya); assert op.last_kernel == "spmm_mix"       # the default on this graph (round 3)
-    op.propagate(x1, yr, force="blk")
+    op.propagate(x1, ya); assert op.last_kernel == "spmm_split"     # the default on this graph (round 4)
+    op.propagate(x1, yr, force="csr")
+    close(ya, yr, rtol=1e-6, atol=2e-6)
+    op.propagate(x1, ya, force="mix"); assert op.last_kernel == "spmm_mix"   # the exact-fp32 choice (round 3)
     close(ya, yr, rtol=1e-6, atol=1e-6)
     op.propagate(x1, yc, force="res"); assert op.last_kernel == "spmm_res"
     close(yc, yr, rtol=1e-6, atol=1e-6)
@@ -984,7 +937,7 @@ def test_partitioned_blocks_with_halo_on_one_gpu(world):
         assert blk.n_halo > 0
         xo = x[:, blk.lo:blk.hi].cuda().contiguous()
         recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()      # [rows, T, D]
-        for force in ("csr", "tiled", "mfma", "pipe", "res", "blk", "mix"):
+        for force in ("csr", "tiled", "res", "mix"):
             y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
             blk.op.propagate(xo, y, force=force, halo=recv.permute(1, 0, 2))
             close(y, ref[:, blk.lo:blk.hi])
@@ -1210,7 +1163,8 @@ def test_config_c3_at_its_own_shape():
     ops = spatial_operators(ei, ew, n)
     probe = torch.empty(1, n, 64, device="cuda")
     ops[0].propagate(out[:1, :, :64], probe)
-    assert ops[0].last_kernel in ("spmm_mix", "spmm_res", "spmm_pipe") and torch.equal(probe, out[:1, :, 64:128])
+    assert ops[0].last_kernel in ("spmm_split", "spmm_mix", "spmm_res")
+    close(probe, out[:1, :, 64:128], rtol=1e-6, atol=1e-6)     # (the encoder passed its bound, this call measured one)
     ref = O.sgp_encoder_forward(x[:48], ei, ew, layers_of(enc.reservoir), k, sparse=True)
     close(out[:48], ref)
     steps = torch.tensor([0, 47, 48, 1000, 2015], device="cuda")

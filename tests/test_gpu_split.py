@@ -163,7 +163,7 @@ def test_split_is_not_chosen_where_it_cannot_serve():
 
 def test_split_encoder_matches_the_oracle_and_the_exact_kernels(monkeypatch):
     """SGPEncoder on a graph large enough for the split hop: against the CPU oracle (1e-5) and against the
-    same encoder with SGP_HOP=exact."""
+    same encoder with SGP_TUNE=hop=exact."""
     import sgp_amd
     from oracle import sgp_oracle as O
     from test_gpu_parity import layers_of
@@ -178,7 +178,7 @@ def test_split_encoder_matches_the_oracle_and_the_exact_kernels(monkeypatch):
     ref = O.sgp_encoder_forward(x, ei, ew, layers_of(enc.reservoir), 3, bidirectional=True, global_attr=True,
                                 sparse=True)
     close(y, ref)
-    monkeypatch.setenv("SGP_HOP", "exact")
+    monkeypatch.setenv("SGP_TUNE", "hop=exact")
     y_exact = enc(x.cuda(), ei, ew).cpu()
     close(y, y_exact, rtol=1e-6, atol=1e-6)
 

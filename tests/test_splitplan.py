@@ -21,16 +21,14 @@ def _plan(op, **kw):
 
 def _check_limits(plan, n_rows, waves=8, chunks=9, max_union=768):
     hdr = plan.hdr.numpy()
-    row0, cnt, union = hdr[:, :waves], hdr[:, waves:2 * waves], hdr[:, 2 * waves]
+    cnt, union = hdr[:, waves:2 * waves], hdr[:, 2 * waves]
     assert cnt.max() <= 32 and cnt.min() >= 0 and union.max() <= max_union
     assert int(cnt.sum()) == n_rows
-    # waves cover the rows once, in order
-    flat = [(int(r), int(c)) for r, c in zip(row0.reshape(-1), cnt.reshape(-1)) if c > 0]
-    nxt = 0
-    for r, c in flat:
-        assert r == nxt
-        nxt = r + c
-    assert nxt == n_rows
+    # every row sits in exactly one slot; a wave's slots are filled from 0
+    rowid = plan.rowid.numpy()
+    assert sorted(rowid[rowid >= 0].tolist()) == list(range(n_rows))
+    assert ((rowid >= 0).sum(2) == cnt).all()
+    assert ((rowid >= 0) == (np.arange(32) < cnt[:, :, None])).all()
     ucol = plan.ucol.numpy()
     for t in range(plan.n_tiles):
         u = int(union[t])
@@ -105,3 +103,21 @@ def test_split_fp16_pieces():
     assert (err <= np.maximum(np.abs(v) * 2.0 ** -21, 2.0 ** -25)).all()
     big = np.abs(v) >= 2.0 ** -14
     assert (np.abs(hi.astype(np.float32))[big] <= np.abs(v)[big]).all()      # truncated towards zero
+
+
+def test_locality_order_serves_scrambled_numberings():
+    """Scrambled node labels: dealt in the given numbering a wave's 32 rows share nothing (few rows per wave,
+    many staged rows per result row); dealt in a locality order of the graph the plan is as good as on the
+    ordered graph -- and still addresses rows and columns by their original ids."""
+    n = 3000
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=6)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    op = _op(perm[ei], ew, n)
+    plain = _plan(op)
+    order = graph.locality_order(op.rowptr.numpy(), op.col.numpy(), n)
+    plan = _plan(op, order=order)
+    assert plan.stats["rows_per_wave"] > 2 * plain.stats["rows_per_wave"]
+    assert plan.stats["staged_per_row"] < 0.5 * plain.stats["staged_per_row"]
+    _check_limits(plan, n)
+    dense = op.to_dense().numpy().astype(np.float64)
+    assert np.abs(splitplan.plan_matrix(plan, n, n) - dense).max() <= 2.0 ** -21 * dense.max()

@@ -4,5 +4,5 @@
 export SGP_AMD_LIB=$PWD/tools/variants/abl/libsgp_amd.so
 for k in mix res; do for v in 0 512 1024 1; do
   echo "$k ABL $v"
-  SGP_PIPE_ABL=$v timeout 200 python tools/probe_mix.py 100000 512 5 $k 2>&1 | grep "^$k"
+  SGP_TUNE=abl=$v timeout 200 python tools/probe_mix.py 100000 512 5 $k 2>&1 | grep "^$k"
 done; done

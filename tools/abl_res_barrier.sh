@@ -5,5 +5,5 @@
 export SGP_AMD_LIB=$PWD/tools/variants/abl/libsgp_amd.so
 for v in 0 256 512 768 1 257; do
   echo "ABL $v"
-  SGP_PIPE_ABL=$v timeout 200 python tools/probe_mix.py 100000 512 5 res 2>&1 | grep "^res"
+  SGP_TUNE=abl=$v timeout 200 python tools/probe_mix.py 100000 512 5 res 2>&1 | grep "^res"
 done

@@ -7,8 +7,8 @@ ROOTD=$PWD
 for v in 0 1; do
   OUT=$ROOTD/gpurun_out/prof_abl_clock_$v
   mkdir -p $OUT
-  (cd /tmp && SGP_PIPE_ABL=$v rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $ROOTD/tools/prof_kernels.py spmm 128 > $OUT/trace.log 2>&1)
-  (cd /tmp && SGP_PIPE_ABL=$v rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/pmc -o p -- python $ROOTD/tools/prof_kernels.py spmm 128 > $OUT/pmc.log 2>&1)
+  (cd /tmp && SGP_TUNE=abl=$v rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/trace -o t -- python $ROOTD/tools/prof_kernels.py spmm 128 > $OUT/trace.log 2>&1)
+  (cd /tmp && SGP_TUNE=abl=$v rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY -d $OUT/pmc -o p -- python $ROOTD/tools/prof_kernels.py spmm 128 > $OUT/pmc.log 2>&1)
   echo "== ABL $v"
   grep spmm_res $OUT/trace/*kernel_stats.csv | cut -c1-160
   python tools/summarize_prof.py $OUT 2>/dev/null | grep -A5 "kernel: void (anonymous namespace)::spmm_res" | head -8

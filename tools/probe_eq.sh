@@ -1,10 +1,10 @@
 #!/bin/bash
-# Equal-cost tiles (SGP_EQUAL_COST_TILES=1) vs uniform tiles for spmm_res: time and fabric reads.
+# Equal-cost tiles (SGP_TUNE=equal_cost_tiles=1) vs uniform tiles for spmm_res: time and fabric reads.
 export TMPDIR=/tmp SGP_PROBE_CHECK=${CHECK:-1} SGP_PROBE_T=${T:-512} SGP_PROBE_KERNELS=res
 ROOTD=$PWD
 for eq in 0 1; do
   for q in ${QS:-0.15}; do
-  export SGP_EQUAL_COST_TILES=$eq SGP_EQUAL_COST_Q=$q
+  export SGP_TUNE=equal_cost_tiles=$eq,equal_cost_q=$q
   echo "equal-cost $eq q=$q: $(timeout 300 python $ROOTD/tools/probe_blk.py 2>&1 | grep -E 'cfg=|csr')"
   if [ "${PMC:-1}" = 1 ]; then
   (cd /tmp && SGP_PROBE_CHECK=0 SGP_PROBE_T=256 timeout 300 rocprofv3 --output-format csv --pmc FETCH_SIZE TCC_HIT_sum -d /tmp/eq_${eq}_$q -o p -- python $ROOTD/tools/probe_blk.py > /tmp/eq_${eq}_$q.log 2>&1)

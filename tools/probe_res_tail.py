@@ -1,4 +1,4 @@
-"""Reservoir layer: exact deal + split-J tail (default) against the even deal (SGP_RES_TAIL=0), and the
+"""Reservoir layer: exact deal + split-J tail (default) against the even deal (SGP_TUNE=res_tail=0), and the
 split-J kernel alone on mid-size graphs (SGP_RES_SPLITJ_MAX).  One process per setting (the knobs are read
 once): python tools/probe_res_tail.py N F R T"""
 import os, sys, torch
@@ -18,6 +18,6 @@ for _ in range(5):
     for _ in range(3): res.encode_into(xin, out)
     b.record()
     best = min(best, a.elapsed_ms(b) / 3)
-tag = f"tail={os.environ.get('SGP_RES_TAIL', '1')} splitj_max={os.environ.get('SGP_RES_SPLITJ_MAX', '512')}"
+tag = f"SGP_TUNE={os.environ.get('SGP_TUNE', '')}"
 print(f"N={N} F={F} R={R} T={T} {tag}: {best:.3f} ms  {N * T * 2 * R * (F + R) / best / 1e9:.1f} TF/s  "
       f"checksum {float(out.double().sum()):.6f} {float(out[-1].abs().max()):.6f}", flush=True)

@@ -20,7 +20,7 @@ def main():
         x = torch.randn(T, N, D, device="cuda")
         y = torch.empty_like(x)
         for _ in range(3):
-            op.propagate(x, y, force=os.environ.get("SGP_FORCE", "pipe"))
+            op.propagate(x, y, force=os.environ.get("SGP_FORCE", "split"))
         torch.cuda.synchronize()
     if what in ("res", "both"):
         torch.manual_seed(0)

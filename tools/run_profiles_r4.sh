@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-4 evidence: one bench line + rocprofv3 kernel stats (+ HBM counter passes) per workload, SQ
+# counters and the per-wave timeline of the split-fp16 hop kernel.
+# usage (on the GPU box, from the repo root): bash tools/run_profiles_r4.sh [workloads...]
+set -u
+ROOTD=$PWD
+OUT=$ROOTD/gpurun_out/r4
+mkdir -p $OUT
+for w in ${@:-target}; do
+  steps=3; [ $w = c5 ] && steps=1
+  timeout 600 python bench.py --workload $w --steps $steps --warmup 1 > $OUT/bench_${w}_line.json 2> $OUT/bench_$w.err
+  timeout 900 bash tools/run_prof_cmd.sh r4_$w python $ROOTD/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline
+  cp gpurun_out/prof_r4_$w/summary.txt $OUT/${w}_summary.txt 2>/dev/null
+  cp gpurun_out/prof_r4_$w/trace/*kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
+  echo "== $w"; cat $OUT/bench_${w}_line.json | head -c 700; echo
+done

@@ -1,9 +1,9 @@
 """Debug: per-wave s_memtime timeline of one workgroup of spmm_mix (ablation build:
-tools/build_variant.sh abl -DSGP_ABLATION, SGP_AMD_LIB=tools/variants/abl/libsgp_amd.so, SGP_PIPE_ABL=128;
+tools/build_variant.sh abl -DSGP_ABLATION, SGP_AMD_LIB=tools/variants/abl/libsgp_amd.so, SGP_TUNE=abl=128;
 +1 = no staging DMA)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("SGP_PIPE_ABL", "128")
+os.environ.setdefault("SGP_TUNE", "abl=128")
 import numpy as np, torch
 from sgp_amd import graph, hip, synthetic
 N, T, D = int(os.environ.get("SGP_PROBE_N", 100000)), int(os.environ.get("SGP_PROBE_T", 64)), 64

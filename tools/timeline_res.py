@@ -1,8 +1,8 @@
 """Debug: per-wave s_memtime timeline of one workgroup of spmm_res (ablation build:
-`make EXTRA=-DSGP_ABLATION`, SGP_PIPE_ABL=128; +1 = no staging DMA, +4 = staging from L2-resident rows)."""
+`make EXTRA=-DSGP_ABLATION`, SGP_TUNE=abl=128; +1 = no staging DMA, +4 = staging from L2-resident rows)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("SGP_PIPE_ABL", "128")
+os.environ.setdefault("SGP_TUNE", "abl=128")
 import numpy as np, torch
 from sgp_amd import graph, hip, synthetic
 N, T, D = int(os.environ.get("SGP_PROBE_N", 100000)), int(os.environ.get("SGP_PROBE_T", 64)), 64

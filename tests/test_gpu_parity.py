@@ -1004,7 +1004,10 @@ def test_bench_forced_collectives_take_the_rccl_branch_on_one_rank(tmp_path):
     assert "multi_gpu" in rec and rec["multi_gpu"]["time_chunks_per_hop"] > 1      # the pipelined branch ran
     forced = torch.load(tmp_path / "out_w1_r0.pt")
     d_h = 64
-    assert torch.equal(forced[:, :, :-d_h], plain[:, :, :-d_h])                   # reservoir + every hop block
+    assert torch.equal(forced[:, :, :d_h], plain[:, :, :d_h])                     # reservoir: same kernel, same bits
+    # hop blocks: one rank has no halo, so both runs take the split-fp16 hop -- the plain encoder with the
+    # activation's bound, the partitioned path with a measured one (another power-of-two scale: ~1e-7)
+    close(forced[:, :, d_h:-d_h], plain[:, :, d_h:-d_h], rtol=1e-6, atol=1e-6)
     close(forced[:, :, -d_h:], plain[:, :, -d_h:], rtol=1e-6, atol=1e-6)           # global block
 
 

@@ -48,6 +48,7 @@ def row_ranges(rowptr, n_rows, n_wg, rows_cap):
 
 
 PAD_ROW = 511
+MAX_COLS = 1 << 22           # a plan entry packs the column in 22 bits (the kernel checks the same limit)
 
 
 def deal_rows_to_slots(wg, lrow, blk, bounds, n_blocks):
@@ -90,7 +91,7 @@ def build_colblock_plan(rowptr, col, val, n_rows, n_cols, feat, rows_cap=511, ro
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
-    if n_cols >= 1 << 22:
+    if n_cols >= MAX_COLS:
         return None
     cpb = int(max(256, l2_bytes // (feat * 4)))
     n_blocks = max(1, -(-n_cols // cpb))

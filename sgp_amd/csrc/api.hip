@@ -2,6 +2,7 @@
 #include "common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <mutex>
 
 namespace sgp {
 static thread_local char g_err[512] = "";
@@ -23,6 +24,29 @@ long tune(const char* key, long dflt) {
         while (*p && *p != ',') ++p;
     }
     return dflt;
+}
+unsigned* sync_slot(hipStream_t s) {
+    constexpr int kSlots = 64, kSlotBytes = 256, kDevs = 64;
+    static std::mutex mu;
+    static unsigned char* ring[kDevs] = {};
+    static unsigned next[kDevs] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return nullptr;
+    unsigned char* base;
+    unsigned slot;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (!ring[dev]) {
+            void* p = nullptr;
+            if (hipMalloc(&p, kSlots * kSlotBytes) != hipSuccess) return nullptr;
+            ring[dev] = static_cast<unsigned char*>(p);
+        }
+        base = ring[dev];
+        slot = next[dev]++ % kSlots;
+    }
+    unsigned char* p = base + slot * kSlotBytes;
+    if (hipMemsetAsync(p, 0, kSlotBytes, s) != hipSuccess) return nullptr;
+    return reinterpret_cast<unsigned*>(p);
 }
 }  // namespace sgp
 

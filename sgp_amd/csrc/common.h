@@ -20,6 +20,11 @@ inline int check_launch(const char* what) {
 // SGP_TUNE="key=value,key=value": the one debug / tuning hook (keys: sgp_amd/tune.py); default when absent
 long tune(const char* key, long dflt);
 
+// A zeroed 256-byte device word block for ONE launch's cross-workgroup counters (arrival counts, pacing):
+// slots come from a per-device ring of 64, cleared on the launch stream, so launches in flight on different
+// streams never share a counter.  nullptr when the allocation fails (callers then run unpaced).
+unsigned* sync_slot(hipStream_t s);
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

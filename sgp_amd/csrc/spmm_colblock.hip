@@ -160,13 +160,10 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
     a.pace = nullptr; a.n_arrive = (unsigned)n_wg * (unsigned)(feat / 64);
     {
         int dev = 0, cus = 0;
-        static unsigned* pace_buf[64] = {nullptr};
-        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64 &&
+        if (hipGetDevice(&dev) == hipSuccess &&
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
-            (long long)a.n_arrive <= cus && batch > 1) {
-            if (!pace_buf[dev] && hipMalloc(&pace_buf[dev], 256) != hipSuccess) pace_buf[dev] = nullptr;
-            if (pace_buf[dev] && hipMemsetAsync(pace_buf[dev], 0, 256, s) == hipSuccess) a.pace = pace_buf[dev];
-        }
+            (long long)a.n_arrive <= cus && batch > 1)
+            a.pace = sgp::sync_slot(s);              // this launch's own counter (two launches in flight never share one)
     }
     const size_t lds_bytes = 512 * 256;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_colblock),

@@ -31,26 +31,34 @@ def _rect_dense(a, x3, dst):
     ShiftOperator(rowptr, c, a[r, c], a.shape[0], num_cols=a.shape[1]).propagate_rect(x3, dst)
 
 
-_CONSTANT_CACHE = {}
+_CONSTANT_CACHE = {}          # id(adj) -> (weakref to adj, adj._version, value); a handful of entries at most
 
 
 def _constant_value(adj):
     """The single value of a dense support whose entries are all equal (the reference's global_attr
-    support: 1 / N everywhere), else None.  Looked at once per support object: the N x N matrix is not
-    copied to the host and compared on every batch."""
+    support: 1 / N everywhere), else None.  Looked at once per support object AND version: the N x N matrix
+    is not copied to the host and compared on every batch, a support modified in place is looked at again,
+    and the cache holds the matrices weakly (it never keeps an N x N tensor alive)."""
+    import weakref
     key = id(adj)
+    version = getattr(adj, "_version", None)
     hit = _CONSTANT_CACHE.get(key)
-    if hit is not None and hit[0] is adj:
-        return hit[1]
+    if hit is not None and hit[0]() is adj and hit[1] == version:
+        return hit[2]
     a = torch.as_tensor(adj)
     value = None
     if a.numel():
         c = a.flatten()[0]
         if bool((a == c).all()):
             value = float(c)
-    if len(_CONSTANT_CACHE) > 64:
+    for k in [k for k, v in _CONSTANT_CACHE.items() if v[0]() is None]:      # entries whose tensor is gone
+        del _CONSTANT_CACHE[k]
+    if len(_CONSTANT_CACHE) >= 8:
         _CONSTANT_CACHE.clear()
-    _CONSTANT_CACHE[key] = (adj, value)
+    try:
+        _CONSTANT_CACHE[key] = (weakref.ref(adj), version, value)
+    except TypeError:                                   # (objects that cannot be weakly referenced: not cached)
+        pass
     return value
 
 

@@ -201,12 +201,13 @@ class ShiftOperator:
 
     def colblock_plan(self, feat, device):
         """Column-blocked plan (``sgp_amd.colblock``, kernel ``sgp_spmm_colblock_f32``) for graphs
-        without locality, or None (feature widths that are not multiples of 64, >= 2^23 columns)."""
+        without locality, or None (feature widths that are not multiples of 64, >= ``colblock.MAX_COLS`` = 2^22 columns)."""
         key = ("colblock", feat, str(device))
         if key not in self._plans:
             plan = None
-            if feat % 64 == 0 and self.num_cols < (1 << 23) and self.nnz() > 0:
-                from . import colblock, hip
+            from . import colblock
+            if feat % 64 == 0 and self.num_cols < colblock.MAX_COLS and self.nnz() > 0:
+                from . import hip
                 lib = hip.load()
                 plan = colblock.build_colblock_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
                                                     self.num_nodes, self.num_cols, feat,

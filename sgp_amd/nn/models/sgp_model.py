@@ -35,13 +35,16 @@ class _GroupedLinearFn(torch.autograd.Function):
     weight and bias."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias, source, step, node, groups, activation, p, seed):
+    def forward(ctx, x2, weight, bias, source, step, node, groups, activation, p, seed, cached=None):
         w2 = weight.reshape(weight.shape[0], -1)
         oc, ic = w2.shape[0] // groups, w2.shape[1]
         dev = x2.device if x2 is not None else source.device
-        wd = w2.detach().to(dev, torch.float32)
-        packed = hip.grouped_linear_pack(wd, groups)
-        bd = bias.detach().to(dev, torch.float32).contiguous()
+        if cached is not None:                      # the module's per-(version, device) copies: no repacking per call
+            wd, packed, bd = cached
+        else:
+            wd = w2.detach().to(dev, torch.float32)
+            packed = hip.grouped_linear_pack(wd, groups)
+            bd = bias.detach().to(dev, torch.float32).contiguous()
         y, pre = hip.grouped_linear(x2, packed, bd, groups, ic, oc, activation, step_index=step,
                                     node_index=node, source=source, want_pre=True, dropout_p=p, seed=seed)
         ctx.save_for_backward(x2 if x2 is not None else source, wd, pre, step, node)
@@ -67,7 +70,7 @@ class _GroupedLinearFn(torch.autograd.Function):
             dw = dw.reshape(wshape).to(wdev)
         if ctx.needs_input_grad[2]:
             db = hip.node_sums(dz[None])[0].to(bdev)
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 class SGPInputEncoder(nn.Module):
@@ -77,7 +80,7 @@ class SGPInputEncoder(nn.Module):
             raise ValueError("in_channels must be divisible by groups")      # nn.Conv1d's own check
         if activation not in hip.GL_ACT_CODES:
             raise ValueError(f"Activation '{activation}' not valid.")
-        if not 0. <= float(dropout) < 1.:
+        if not 0. <= float(dropout) <= 1.:                                   # nn.Dropout's own range
             raise ValueError(f"dropout probability has to be between 0 and 1, but got {dropout}")
         self.dropout = float(dropout)
         self.input_size, self.order = int(input_size), int(order)
@@ -90,12 +93,16 @@ class SGPInputEncoder(nn.Module):
         self.weight, self.bias = conv.weight, conv.bias
         self._packed = None
 
-    def _device_params(self, device):
+    def _device_params(self, device, with_weight=False):
+        """Packed weights + bias on ``device``, rebuilt only when a parameter changed (``_version``) -- also for
+        the autograd path (``with_weight``: plus the plain fp32 weight the backward pass transposes)."""
         key = (self.weight._version, self.bias._version, str(device))
         if self._packed is None or self._packed[0] != key:
-            w = self.weight.detach().to(device, torch.float32)
+            w = self.weight.detach().reshape(self.weight.shape[0], -1).to(device, torch.float32)
             self._packed = (key, hip.grouped_linear_pack(w, self.order),
-                            self.bias.detach().to(device, torch.float32).contiguous())
+                            self.bias.detach().to(device, torch.float32).contiguous(), w)
+        if with_weight:
+            return self._packed[3], self._packed[1], self._packed[2]
         return self._packed[1], self._packed[2]
 
     @property
@@ -107,7 +114,9 @@ class SGPInputEncoder(nn.Module):
         return self.out_channels // self.order
 
     def forward(self, x):
-        """x[b, n, f] (or [b, s, n, f]: the last step is used, sgp_model.py:96) -> [b, n, out]."""
+        """x[b, n, f] (or [b, s, n, f]: the last step is used, sgp_model.py:96) -> [b, n, out].  Inference
+        should run under ``torch.no_grad()``: with grad mode on and trainable parameters every call goes
+        through the autograd function (an extra [rows, out] pre-activation buffer)."""
         x = x[:, -1] if x.dim() == 4 else x
         if x.dim() != 3 or x.shape[-1] != self.input_size:
             raise ValueError(f"expected [b, n, {self.input_size}], got {tuple(x.shape)}")
@@ -121,7 +130,10 @@ class SGPInputEncoder(nn.Module):
             rows = rows.contiguous()
         if self._needs_graph(rows):
             y = _GroupedLinearFn.apply(rows, self.weight, self.bias, None, None, None, self.order,
-                                       self.activation, *self._dropout_args())
+                                       self.activation, *self._dropout_args(),
+                                       self._device_params(x.device, with_weight=True))
+            if self.training and self.dropout >= 1.:
+                y = y * 0.                                                   # nn.Dropout(p=1): all zeros
         else:
             packed, bias = self._device_params(x.device)
             y = hip.grouped_linear(rows, packed, bias, self.order, self._ic, self._oc, self.activation)
@@ -130,7 +142,7 @@ class SGPInputEncoder(nn.Module):
 
     def _dropout_args(self):
         """(p, seed): a fresh 63-bit seed from torch's default generator per training-mode call."""
-        if not (self.training and self.dropout > 0.):
+        if not (self.training and 0. < self.dropout < 1.):                   # (p = 1 is applied by the caller)
             return 0., 0
         return self.dropout, int(torch.randint(0, 2 ** 62, (1,)).item())
 
@@ -149,7 +161,10 @@ class SGPInputEncoder(nn.Module):
         nd = node_index.to(embedding.device, torch.int32)
         if self._needs_graph():
             y = _GroupedLinearFn.apply(None, self.weight, self.bias, embedding.detach(), st, nd, self.order,
-                                       self.activation, *self._dropout_args())
+                                       self.activation, *self._dropout_args(),
+                                       self._device_params(embedding.device, with_weight=True))
+            if self.training and self.dropout >= 1.:
+                y = y * 0.
         else:
             packed, bias = self._device_params(embedding.device)
             y = hip.grouped_linear(None, packed, bias, self.order, self._ic, self._oc, self.activation,

@@ -172,15 +172,19 @@ class HaloExchange:
         self._idx = None
 
     def _buffers(self, T, D, device):
+        """Contiguous ``[rows, T, D]`` views of flat buffers that only ever grow: time pieces of unequal length
+        (``encode_partitioned`` cuts T into ``(T * j) // pieces``) re-use one allocation instead of alternating
+        between two shapes."""
         g = self.block.gather_rows
-        shape_s = (g if g else sum(self.block.send_counts), T, D)
-        shape_r = (self.block.n_halo, T, D)
-        if self._send is None or self._send.shape != shape_s or self._send.device != device:
+        rows_s, rows_r = (g if g else sum(self.block.send_counts)), self.block.n_halo
+        need_s, need_r = rows_s * T * D, rows_r * T * D
+        if self._send is None or self._send.device != device or self._send.numel() < need_s \
+                or self._recv.numel() < need_r:
             # (gather form: the rows past a short shard are never referenced, but they travel: keep them finite)
-            self._send = (torch.zeros if g else torch.empty)(shape_s, dtype=torch.float32, device=device)
-            self._recv = torch.empty(shape_r, dtype=torch.float32, device=device)
+            self._send = (torch.zeros if g else torch.empty)(max(need_s, 1), dtype=torch.float32, device=device)
+            self._recv = torch.empty(max(need_r, 1), dtype=torch.float32, device=device)
             self._idx = (torch.arange(self.block.n_own, dtype=torch.int32) if g else self.block.send_index).to(device)
-        return self._send, self._recv
+        return self._send[:need_s].view(rows_s, T, D), self._recv[:need_r].view(rows_r, T, D)
 
     def _all_gather(self, x, send, recv):
         """General case: every rank's full shard (padded to the largest) to every rank."""

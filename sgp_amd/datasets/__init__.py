@@ -1,3 +1,4 @@
 from .iid_dataset import IIDSampler
+from .sharded import ShardedEmbedding, ShardedIIDSampler
 
-__all__ = ["IIDSampler"]
+__all__ = ["IIDSampler", "ShardedEmbedding", "ShardedIIDSampler"]

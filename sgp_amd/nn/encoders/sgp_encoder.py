@@ -332,23 +332,69 @@ class SGPEncoder(nn.Module):
                 sink.close()
         return out
 
+    def encode_to_shards(self, x, ops, shard_dir, shard_steps):
+        """Host tensor x[T, N, F] -> time shards on disk, ``shard_steps`` steps each, never holding more than
+        one shard on the host: embeddings larger than host RAM (configuration C5 is 629 GB,
+        ``experiments/run_largescale_sgp.py:208-212``).  The reservoir state is carried on the device, the
+        propagation is independent per step: the shards are bit-identical to slices of one pass.  Returns a
+        ``sgp_amd.datasets.ShardedEmbedding`` (``load_steps(t0, t1)`` reads any time range back)."""
+        import os
+        from ...datasets.sharded import ShardedEmbedding
+        hip.require_gpu()
+        T, N, F = x.shape
+        os.makedirs(shard_dir, exist_ok=True)
+        dev = torch.device("cuda", torch.cuda.current_device())
+        L, R = len(self.reservoir.reservoir_layers), self.reservoir.hidden_size
+        D = self.output_size
+        per_step = N * (F + D) * 4
+        ts = max(1, min(int(shard_steps), T, self._budget() // max(1, 2 * per_step)))
+        state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
+        buf = torch.empty(ts, N, D, dtype=torch.float32, device=dev)
+        pin = torch.empty(ts, N, D, dtype=torch.float32, pin_memory=True)
+        paths = []
+        for t0 in range(0, T, ts):
+            n = min(ts, T - t0)
+            xs = x[t0:t0 + n].float().to(dev)
+            self.encode_device(xs if xs.stride(2) == 1 else xs.contiguous(), ops, out=buf[:n], state=state)
+            pin[:n].copy_(buf[:n])                                # (synchronous: the shard is complete on the host)
+            path = os.path.join(shard_dir, f"embedding_t{t0:08d}.pt")
+            torch.save(dict(t0=t0, steps=n, rows=None, embedding=pin[:n].clone()), path)
+            paths.append(path)
+        ShardedEmbedding.write_index(shard_dir, paths, (T, N, D))
+        return ShardedEmbedding(paths, T, N, D)
+
     # D2H straight into the (registered) result tensor; False = pinned bounce slots + host memcpy
     register_output = True
 
-    def forward(self, x, edge_index, edge_weight, return_device=False, out=None, gpus=None):
+    def forward(self, x, edge_index, edge_weight, return_device=False, out=None, gpus=None, shard_dir=None,
+                shard_steps=None):
         # x : [t n f]; ``return_device=True`` keeps the embedding of a host input on the GPU
         # (the next row f1 consumes it there: sgp_amd.datasets.IIDDataset); ``out``: host tensor
         # [t, n, d_out] to fill (host inputs only; see encode_streamed); ``gpus``: number of GPUs the
         # graph is node-partitioned over (None: SGP_AMD_GPUS, default 1; 0 / "all": every visible GPU) --
         # the call stays a single-process call on a host tensor, the ranks are started and joined inside
         # (sgp_amd/multigpu.py)
+        # ``shard_dir``: write the embedding as shard files instead of returning one host tensor (embeddings
+        # larger than host RAM) -- time shards of ``shard_steps`` steps on one GPU, time x node-block shards of
+        # the ranks with ``gpus`` > 1; the call then returns a ``sgp_amd.datasets.ShardedEmbedding``
         from ... import multigpu
         n_gpus = multigpu.resolve_gpus(gpus)
         if n_gpus > 1:
             if x.is_cuda or return_device:
                 raise ValueError("gpus > 1 takes a host tensor and returns a host tensor in the original node "
                                  "order (device shards live in the rank processes)")
+            if shard_dir is not None:
+                from ...datasets.sharded import ShardedEmbedding
+                paths = multigpu.encode_multi_gpu(self, x, edge_index, edge_weight, n_gpus, shard_dir=shard_dir)
+                shape = (x.shape[0], x.shape[1], self.output_size)
+                ShardedEmbedding.write_index(shard_dir, paths, shape)
+                return ShardedEmbedding(paths, *shape)
             return multigpu.encode_multi_gpu(self, x, edge_index, edge_weight, n_gpus, out=out)
+        if shard_dir is not None:
+            if x.is_cuda or return_device or out is not None:
+                raise ValueError("shard_dir takes a host tensor and writes shard files")
+            ops = self.sgp_encoder.operators(x.size(-2), edge_index, edge_weight)
+            return self.encode_to_shards(x, ops, shard_dir, shard_steps or 256)
         dev = x.device
         ops = self.sgp_encoder.operators(x.size(-2), edge_index, edge_weight)
         xg = x.float()

@@ -13,7 +13,7 @@ logger = logging.getLogger("sgp_amd")
 
 
 def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True,
-                   keep_raw=False, save_path=None, return_device=False, gpus=None):
+                   keep_raw=False, save_path=None, return_device=False, gpus=None, shard_steps=None):
     """lib/utils.py:10-47.  ``dataset`` is any object with the slice of the
     ``tsl.data.SpatioTemporalDataset`` interface the harness touches: ``exogenous``,
     ``get_tensors``, ``edge_index``, ``edge_weight``, ``add_exogenous``, ``set_input_map``.
@@ -29,7 +29,10 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     saves the tensor only, the random weights are lost); ``gpus=N`` (default: SGP_AMD_GPUS, else 1)
     node-partitions the graph over N GPUs behind the same single-process call (``sgp_amd/multigpu.py``:
     one rank per GPU is started and joined inside, the embedding comes back as one host tensor in the
-    dataset's node order)."""
+    dataset's node order); ``shard_steps=S`` with ``save_path`` a DIRECTORY streams the embedding to disk in
+    time shards of S steps (never holding more than one on the host: embeddings larger than host RAM, the
+    629 GB of ``run_largescale_sgp.py:208-212``) instead of the reference's single ``torch.save``
+    (lib/utils.py:34-35); ``encoded_x`` is then a ``sgp_amd.datasets.ShardedEmbedding``."""
     exo_keys = _exogenous_to_encode(dataset, encode_exogenous)
     x, _ = dataset.get_tensors(['data'] + exo_keys, preprocess=True, cat_dim=-1)
     encoder = encoder_class(**encoder_kwargs)
@@ -40,7 +43,12 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
         hip.require_gpu()
         x = x.cuda()
     from .multigpu import resolve_gpus
-    if resolve_gpus(gpus) > 1:
+    if shard_steps is not None:
+        if save_path is None or return_device:
+            raise ValueError("shard_steps needs save_path (a directory) and a host embedding")
+        embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight, gpus=gpus,
+                            shard_dir=str(save_path), shard_steps=int(shard_steps))
+    elif resolve_gpus(gpus) > 1:
         if return_device:
             raise ValueError("return_device=True keeps ONE device tensor: use gpus=1")
         embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight, gpus=gpus)
@@ -50,9 +58,14 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     logger.info(f"Dataset encoded in {seconds // 60}:{seconds % 60:02d} minutes.")
 
     if save_path is not None:
-        torch.save(embedding, save_path)
-        if hasattr(encoder, "describe"):
-            torch.save(encoder.describe(), str(save_path) + ".encoder.pt")
+        if shard_steps is not None:
+            import os
+            if hasattr(encoder, "describe"):
+                torch.save(encoder.describe(), os.path.join(str(save_path), "encoder.pt"))
+        else:
+            torch.save(embedding, save_path)
+            if hasattr(encoder, "describe"):
+                torch.save(encoder.describe(), str(save_path) + ".encoder.pt")
 
     # the embedding becomes the model input 'x'; what was not encoded stays available as 'u'
     dataset.add_exogenous('encoded_x', embedding, add_to_input_map=False)

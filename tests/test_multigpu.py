@@ -132,3 +132,73 @@ def test_shard_dir_writes_rank_shards_instead_of_a_host_tensor(tmp_path):
         s = torch.load(p)
         got[s["t0"]:s["t0"] + s["steps"]].index_copy_(1, s["rows"], s["embedding"])
     assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------ shards on disk, node-sharded sampling
+@pytest.mark.gpu
+def test_encode_dataset_streams_time_shards_to_disk(tmp_path):
+    """``encode_dataset(save_path=dir, shard_steps=S)``: time shards on disk + encoder description, equal to
+    slices of the one-tensor embedding; ``encoded_x`` is a ShardedEmbedding that reads any range back."""
+    from sgp_amd.datasets import ShardedEmbedding
+    from test_host_logic import FakeDataset
+    n, t = 700, 50
+    ei, ew, _ = synthetic.knn_graph(n, 10, seed=1)
+    ds = FakeDataset(torch.randn(t, n, 1), torch.randn(t, 2), ei, ew)
+    kw = dict(input_size=3, reservoir_size=16, reservoir_layers=1, leaking_rate=.9, spectral_radius=.9,
+              density=.7, input_scaling=1., receptive_field=2, bidirectional=False, alpha_decay=False,
+              global_attr=True)
+    torch.manual_seed(5)
+    sgp_amd.encode_dataset(ds, sgp_amd.SGPEncoder, kw, save_path=str(tmp_path / "emb"), shard_steps=16)
+    sharded = ds._t["encoded_x"]
+    assert isinstance(sharded, ShardedEmbedding) and sharded.shape == (t, n, 16 * 4) and len(sharded.paths) == 4
+    desc = torch.load(tmp_path / "emb" / "encoder.pt")
+    twin = sgp_amd.SGPEncoder(**desc["kwargs"]); twin.load_state_dict(desc["state_dict"])
+    x, _ = ds.get_tensors(["data", "u"], preprocess=True, cat_dim=-1)
+    full = twin(x, ei, ew)
+    assert torch.equal(sharded.load_steps(0, t), full)
+    assert torch.equal(sharded.load_steps(10, 37), full[10:37])
+    again = ShardedEmbedding.from_dir(str(tmp_path / "emb"))
+    assert again.shape == sharded.shape and torch.equal(again.load_steps(40, 50), full[40:])
+
+
+@pytest.mark.gpu
+def test_sharded_embedding_from_rank_shards(tmp_path):
+    n, t = 2200, 24
+    ei, ew, _ = synthetic.knn_graph(n, 20, seed=4)
+    enc = _encoder(seed=6, reservoir_layers=1)
+    x = torch.randn(t, n, 3, generator=torch.Generator().manual_seed(3))
+    ref = enc(x, ei, ew)
+    sharded = enc(x, ei, ew, gpus=2, shard_dir=str(tmp_path))
+    assert sharded.shape == tuple(ref.shape)
+    got = sharded.load_steps(0, t)
+    assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cut", [2, 3])
+def test_sharded_iid_sampler_equals_the_reference_fixture(cut):
+    """g7 fixtures (the reference's own ``IIDDataset.sample`` output) through node shards == g7: the index
+    sequence is drawn once as the reference draws it, every shard gathers its own rows on the device."""
+    import numpy as np
+    from conftest import GOLDEN, golden_files
+    from sgp_amd.datasets import ShardedIIDSampler
+    for name in golden_files("g7_iid_"):
+        z = np.load(os.path.join(GOLDEN, name))
+        hz, delay, lag, nb = [int(v) for v in z["cfg"]]
+        emb, y, u = (torch.from_numpy(z[k]) for k in ("emb", "y", "u"))
+        n = emb.shape[1]
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(cut))     # shards own scattered nodes
+        ids = [perm[i::cut] for i in range(cut)]
+        s = ShardedIIDSampler(emb.shape[0], n, hz, delay, lag)
+        s.add_input_shards("x", [(i, emb[:, i].contiguous().cuda()) for i in ids])
+        if bool(z["has_exo"]):
+            s.add_input("u", u, "t f", preprocess=False)
+        s.add_target_shards("y", [(i, y[:, i].contiguous().cuda()) for i in ids])
+        torch.manual_seed(int(z["seed"]))
+        out = s.sample(nb)
+        assert np.array_equal(out["input"]["node_index"].numpy(), z["out_node_index"])
+        assert np.array_equal(out["input"]["x"].cpu().numpy(), z["out_x"])
+        if not bool(z["has_scaler"]):
+            assert np.array_equal(out["target"]["y"].cpu().numpy(), z["out_y"])
+        if bool(z["has_exo"]):
+            assert np.array_equal(out["input"]["u"].cpu().numpy(), z["out_u"])

@@ -399,9 +399,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32" if tune.get("hop", "split") != "split" or world > 1 else
-                     "f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per product, fp32 "
-                     "accumulation -- agrees with fp32 to ~1e-7 of the operand scale; reservoir: exact fp32 MFMA)",
+            "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{args.workload}: N={N} nodes, T={T} steps, F_in={F}, "
                                    f"reservoir {R}x{L}, K={K}, "
@@ -428,6 +426,10 @@ def main():
             traffic, source = profiled_traffic(args.workload, kernel)
             if traffic is not None and pieces > 1:
                 traffic /= pieces                          # (profiled per launch of the same size)
+            if kernel == "spmm_split":
+                rec["dtype"] = ("f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per "
+                                "product, fp32 accumulation -- agrees with fp32 to ~1e-7 of the operand scale; "
+                                "reservoir: exact fp32 MFMA)")
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": source,

@@ -35,7 +35,10 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 using sgp::f32x4;
 
 constexpr int NW = 8;                        // waves per workgroup
-constexpr int NCH = 9;                       // resident 32-column chunks per wave
+#ifndef SGP_SPLIT_NCH
+#define SGP_SPLIT_NCH 9
+#endif
+constexpr int NCH = SGP_SPLIT_NCH;           // resident 32-column chunks per wave (experiment builds: -DSGP_SPLIT_NCH=..)
 constexpr int SMAX = 768;                    // staged rows per tile
 constexpr int NLD = SMAX / (16 * NW);        // 6 LDS-DMA instructions per wave and unit (16 rows each)
 constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
@@ -84,6 +87,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {       // n is wave-uniform, 0
     }
 }
 static_assert(NCH >= 2, "the operand ring is primed with two chunks");
+static_assert(NLD <= NCH, "one staging piece per chunk of the MFMA phase");
 static_assert(NLD == 6, "wait_vm_n covers 0 .. 6 outstanding pieces");
 
 // v * s = hi + lo: hi by truncation (v_cvt_pkrtz: the remainder is then exact in fp32), lo rounded
@@ -113,7 +117,6 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int* hd = a.hdr + (size_t)tile * HDR;
     const int src_tile = (a.mode & 16) ? xcd * a.tiles_per_xcd : tile;   // 16: every tile of an XCD stages the same rows
     const int nU = __builtin_amdgcn_readfirstlane(a.hdr[(size_t)src_tile * HDR + 2 * NW]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -204,7 +207,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     int t = t_begin, sl = 0, cur = 0;
-    const bool late = (wave >> 2) != 0 && !(a.mode & 128);    // 128: every wave multiplies first
+    // measured (T = 512, target graph): all eight waves in the same order 17.6 ms per hop, the two waves of a SIMD in
+    // opposite order (one multiplies while the other converts) 18.3 -- mode 128 selects the opposite order
+    const bool late = (wave >> 2) != 0 && (a.mode & 128);
     f32x4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
     auto stamp = [&](int u, int k) {
         if ((a.mode & 256) && blockIdx.x == 0 && lane == 0 && u >= 16 && u < 24)
@@ -215,14 +220,21 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         const int nxt = cur == NBUF - 1 ? 0 : cur + 1;
         const int nn = nxt == NBUF - 1 ? 0 : nxt + 1;
         const bool more2 = u + 2 < n_units;
-        if (more2 && !(a.mode & 1)) { issue_dma(dt, dsl, nn); advance(dt, dsl); }
+        // the six pieces of unit u + 2 are requested one per chunk INSIDE the MFMA phase: a piece whose issue stalls on
+        // a full memory queue then waits under matrix-core work that is already queued, not in front of it
+        const bool dma_now = more2 && !(a.mode & 1);
+        const float* xb2 = (a.mode & 64) ? a.X : a.X + (long long)dt * a.xbs + dsl * 16;
+        const unsigned base2 = lds0 + nn * BUF + wave * 1024;
+        if (dma_now) advance(dt, dsl);
 
         stamp(u, 1);
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         auto stage_next = [&]() {
             if (u + 1 < n_units) {
                 // the pieces of unit u + 1 were requested a whole unit ago; only the nld newest (unit u + 2) may stay in flight
-                if (more2 && !(a.mode & 1)) wait_vm_n(nld); else wait_vm<0>();
+                // early waves (multiply first): only the nld pieces just requested (unit u + 2) may stay in flight;
+                // late waves convert BEFORE they request this unit's pieces: everything of theirs has to be back
+                if (dma_now && !late) wait_vm_n(nld); else wait_vm<0>();
                 if (!(a.mode & 8)) convert(nxt);
             }
         };
@@ -249,7 +261,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bl, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][3], bh, acc1, 0, 0, 0);
+                if (c < NLD && dma_now && c < nld) dma16(xoff[c], xb2, base2 + c * (NW * 1024));
             }
+        } else if (dma_now) {
+#pragma unroll
+            for (int i = 0; i < NLD; ++i)
+                if (i < nld) dma16(xoff[i], xb2, base2 + i * (NW * 1024));
         }
         stamp(u, 3);
         if (!late) stage_next();

@@ -19,8 +19,7 @@ Library (integers)
     abl=0                   ablation bits of res / mix (only in builds with -DSGP_ABLATION)
     split_abl=0             ablation bits of sgp_spmm_split_f32 (1 no loads, 2 no MFMAs, 4 no stores, 8 no
                             conversion, 16 shared rows per XCD, 32 unpaired stores, 64 always step 0,
-                            128 same phase order for all waves, 256 per-wave timeline of workgroup 0)
-    split_sync=1            rounds of an XCD's workgroups start together (persistent launch)
+                            128 the two waves of a SIMD take the phases in opposite order, 256 per-wave timeline of workgroup 0)
     gesn_persistent=1, gesn_dbg=0, stack_debug=0, res_splitj_max, res_tail=1   reservoir / DynGESN experiments
 """
 import os

@@ -21,7 +21,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); fn(); e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1))
-    print(f"ABL={os.environ.get("SGP_TUNE", ""):>3} T={T} tc={tc}: {best:.3f} ms  ({best * 1024 / T:.2f} per 1024 steps)", flush=True)
+    print(f"SGP_TUNE={os.environ.get('SGP_TUNE', '')} T={T} tc={tc}: {best:.3f} ms  ({best * 1024 / T:.2f} per 1024 steps)", flush=True)
 else:
     for m in sys.argv[1:] or ["0", "1", "2", "4", "8", "3", "9", "13", "6", "14"]:
-        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, SGP_TUNE="split_abl=" + m))
+        subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, SGP_TUNE=",".join(v for v in (os.environ.get("SGP_TUNE", ""), "split_abl=" + m) if v)))

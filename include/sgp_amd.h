@@ -192,12 +192,13 @@ int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride
  *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
  *   afr[n_tiles][8][chunks][4][64][8] fp16   A fragments in lane order (2 * half + piece)
  *   adr[n_tiles][8][chunks][2][64]           per-lane plane byte address of the transpose reads
- * with chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0; no halo
- * source.  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
+ * with chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0.  X / X_halo /
+ * n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows a node partition received).  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
  * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */
 int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
                        const int32_t* adr, int32_t n_tiles,
                        const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                       const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                        float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream);

@@ -49,6 +49,8 @@ struct SplitArgs {
     const int* hdr; const int* rowid; const int* ucol; const h8* afr; const int* adr;
     int n_tiles, tiles_per_xcd;
     const float* X; long long xrs, xbs;
+    const float* XH; long long xhrs, xhbs;   // halo source (columns >= n_own): local block of a node partition
+    int n_own;
     float* Y; long long yrs, ybs;
     int batch, nslice, t_chunk;
     float x_scale, inv_scale;
@@ -78,6 +80,11 @@ __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned
                  :: "v"(voff), "s"(sbase), "s"(lds_off) : "memory");   // m0 is a reserved register: hipcc rejects it in a clobber list and never keeps a value in it across an asm
 }
 
+// the same with a full per-lane address (two sources: own rows and halo rows)
+__device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vaddr), "s"(lds_off) : "memory");
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void wait_vm_n(int n) {       // n is wave-uniform, 0 .. NLD
     switch (n) {
@@ -102,6 +109,7 @@ __device__ __forceinline__ void split4(const f32x4 v, const float s, uint2& hi, 
     lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
+template <bool HALO>
 __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
@@ -144,7 +152,10 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     for (int i = 0; i < NLD; ++i) {
         const int s = (i * NW + wave) * 16 + (lane >> 2);
         const int c = uc[s < nU ? s : 0];
-        xoff[i] = (unsigned)(c * a.xrs * 4 + (lane & 3) * 16);
+        if (HALO && c >= a.n_own)                              // bit 31 marks a halo row (offsets stay below 2^31)
+            xoff[i] = 0x80000000u | (unsigned)((c - a.n_own) * a.xhrs * 4 + (lane & 3) * 16);
+        else
+            xoff[i] = (unsigned)(c * a.xrs * 4 + (lane & 3) * 16);
         if ((i * NW + wave) * 16 < nU) nld = i + 1;
     }
     wait_vm<0>();                                             // the plan loads above: from here on vmcnt is counted by hand
@@ -156,12 +167,21 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     // group has returned before its first write goes out.
     const int cv_off = wave * 1024 + (lane >> 5) * 512 + ((lane >> 2) & 7) * 32 + (lane & 3) * 8;
 
+    auto piece = [&](unsigned off, const float* xb, const float* xh, unsigned lds_off) {
+        if constexpr (HALO) {
+            const char* b = (off & 0x80000000u) ? (const char*)xh : (const char*)xb;
+            dma16_vaddr(b + (off & 0x7fffffffu), lds_off);
+        } else {
+            dma16(off, xb, lds_off);
+        }
+    };
     auto issue_dma = [&](int t, int sl, int buf) {
         const float* xb = (a.mode & 64) ? a.X : a.X + (long long)t * a.xbs + sl * 16;   // 64: always step 0 (all L2 hits)
+        const float* xh = HALO ? a.XH + (long long)t * a.xhbs + sl * 16 : nullptr;
         const unsigned base = lds0 + buf * BUF + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (i < nld) dma16(xoff[i], xb, base + i * (NW * 1024));
+            if (i < nld) piece(xoff[i], xb, xh, base + i * (NW * 1024));
     };
     auto convert = [&](int buf) {
         char* rb = lds + buf * BUF;
@@ -224,6 +244,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         // a full memory queue then waits under matrix-core work that is already queued, not in front of it
         const bool dma_now = more2 && !(a.mode & 1);
         const float* xb2 = (a.mode & 64) ? a.X : a.X + (long long)dt * a.xbs + dsl * 16;
+        const float* xh2 = HALO ? a.XH + (long long)dt * a.xhbs + dsl * 16 : nullptr;
         const unsigned base2 = lds0 + nn * BUF + wave * 1024;
         if (dma_now) advance(dt, dsl);
 
@@ -261,12 +282,12 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bl, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][3], bh, acc1, 0, 0, 0);
-                if (c < NLD && dma_now && c < nld) dma16(xoff[c], xb2, base2 + c * (NW * 1024));
+                if (c < NLD && dma_now && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024));
             }
         } else if (dma_now) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
-                if (i < nld) dma16(xoff[i], xb2, base2 + i * (NW * 1024));
+                if (i < nld) piece(xoff[i], xb2, xh2, base2 + i * (NW * 1024));
         }
         stamp(u, 3);
         if (!late) stage_next();
@@ -307,6 +328,7 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
                                   const int32_t* adr,
                                   int32_t n_tiles,
                                   const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                                  const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                                   float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                                   int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                                   float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream) {
@@ -317,13 +339,19 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     SGP_REQUIRE(sgp::aligned16(X) && x_row_stride % 4 == 0 && x_batch_stride % 4 == 0 &&
                 sgp::aligned16(Y) && y_row_stride % 4 == 0 && y_batch_stride % 4 == 0,
                 "spmm_split: X and Y rows must be 16-byte aligned");
-    SGP_REQUIRE((long long)n_cols * x_row_stride < (1ll << 29) && (long long)n_rows * y_row_stride < (1ll << 40),
-                "spmm_split: source rows beyond 32-bit byte offsets");
+    {
+        const long long own = X_halo ? n_own : n_cols, far = X_halo ? n_cols - n_own : 0;
+        SGP_REQUIRE(own >= 0 && far >= 0 && own * x_row_stride < (1ll << 29) && far * xh_row_stride < (1ll << 29) &&
+                    (long long)n_rows * y_row_stride < (1ll << 40), "spmm_split: source rows beyond 31-bit byte offsets");
+        SGP_REQUIRE(!X_halo || (sgp::aligned16(X_halo) && xh_row_stride % 4 == 0 && xh_batch_stride % 4 == 0),
+                    "spmm_split: halo rows must be 16-byte aligned");
+    }
     SGP_REQUIRE(x_scale > 0.f && w_scale > 0.f, "spmm_split: scales must be positive");
     SplitArgs a;
     a.hdr = hdr; a.rowid = rowid; a.ucol = ucol; a.afr = (const h8*)afr; a.adr = adr;
     a.n_tiles = n_tiles; a.tiles_per_xcd = (n_tiles + 7) / 8;
     a.X = X; a.xrs = x_row_stride; a.xbs = x_batch_stride;
+    a.XH = X_halo; a.xhrs = xh_row_stride; a.xhbs = xh_batch_stride; a.n_own = X_halo ? n_own : 0x7fffffff;
     a.Y = Y; a.yrs = y_row_stride; a.ybs = y_batch_stride;
     a.batch = batch; a.nslice = feat / 16;
     if (t_chunk <= 0) {
@@ -338,21 +366,17 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     a.dbg = nullptr;
     if (abl & 256) { if (hipMalloc(&a.dbg, 8 * NW * 8 * 8) != hipSuccess) return sgp::fail(SGP_EINVAL, "dbg alloc"); (void)hipMemset(a.dbg, 0, 8 * NW * 8 * 8); }
     const int n_tchunks = (batch + t_chunk - 1) / t_chunk;
-    static bool attr_set[64] = {};
-    int dev = 0; (void)hipGetDevice(&dev);
-    if (dev < 64 && !attr_set[dev]) {
-        hipError_t e = hipFuncSetAttribute((const void*)spmm_split, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * BUF);
-        if (e != hipSuccess) return sgp::fail((int)e, "spmm_split: LDS attribute: %s", hipGetErrorString(e));
-        attr_set[dev] = true;
-    }
+    auto kern = X_halo ? spmm_split<true> : spmm_split<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * BUF);
+    if (e != hipSuccess) return sgp::fail((int)e, "spmm_split: LDS attribute: %s", hipGetErrorString(e));
     const unsigned grid = 8u * (unsigned)a.tiles_per_xcd * (unsigned)n_tchunks;
-    hipLaunchKernelGGL(spmm_split, dim3(grid), dim3(NW * 64), NBUF * BUF, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), NBUF * BUF, (hipStream_t)stream, a);
     if (abl & 256) {
         unsigned long long h[8 * NW * 8];
         (void)hipDeviceSynchronize();
         (void)hipMemcpy(h, a.dbg, sizeof(h), hipMemcpyDeviceToHost);
         (void)hipFree(a.dbg);
-        printf("spmm_split timeline (cycles since the unit's top; columns: dma issued | first phase done | MFMAs / second phase | .. | stores | barrier)\n");
+        printf("spmm_split timeline (cycles since the unit's top; columns: top | first phase start | MFMAs start | MFMAs done | staged | stores | barrier)\n");
         for (int u = 0; u < 8; ++u) for (int w = 0; w < NW; ++w) {
             const unsigned long long* r = h + (u * NW + w) * 8;
             printf("  unit %d wave %d: top %llu |", u, w, r[0] - h[0]);

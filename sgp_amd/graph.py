@@ -254,7 +254,7 @@ class ShiftOperator:
         key = ("split", str(device))
         if key not in self._plans:
             plan = None
-            if self.num_cols == self.num_nodes and self.nnz() > 0:
+            if self.nnz() > 0:
                 from . import hip, splitplan
                 lib = hip.load()
                 lim = dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
@@ -263,7 +263,8 @@ class ShiftOperator:
                 plan = splitplan.build_split_plan(*args, **lim)
                 # numberings without locality (32 consecutive rows share no columns): deal the rows in a
                 # locality order of the graph itself, as the tile plans do
-                if plan is not None and plan.stats["rows_per_wave"] < 24 and self.num_nodes >= 2048:
+                if plan is not None and plan.stats["rows_per_wave"] < 24 and self.num_nodes >= 2048 and \
+                        self.num_cols == self.num_nodes:
                     alt = splitplan.build_split_plan(*args, order=locality_order(
                         self.rowptr.numpy(), self.col.numpy(), self.num_nodes), **lim)
                     if alt is not None and alt.stats["staged_per_row"] < plan.stats["staged_per_row"]:
@@ -279,11 +280,11 @@ class ShiftOperator:
     def split_eligible(self, x, y, halo=None):
         """Whether ``propagate`` would pick the split-fp16 hop on its own for these operands (callers that
         know a bound on |x| pass it; others let ``propagate`` measure one)."""
-        return (halo is None and tune.get("hop", "split") == "split"
-                and self.num_cols == self.num_nodes and x.is_cuda
-                and x.shape[2] % 16 == 0 and x.shape[1] * max(x.stride(1), 1) < 2 ** 29
-                and x.stride(1) % 4 == 0 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
-                and y.stride(1) % 4 == 0 and y.stride(0) % 4 == 0 and y.data_ptr() % 16 == 0
+        def ok(t):
+            return t.is_cuda and t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and \
+                t.shape[1] * max(t.stride(1), 1) < 2 ** 29
+        return (tune.get("hop", "split") == "split" and ok(x) and ok(y) and (halo is None or ok(halo))
+                and x.shape[2] % 16 == 0
                 and self.nnz() >= 8 * self.num_nodes and self.num_nodes >= 2048
                 and self.split_plan(x.device) is not None)
 
@@ -329,15 +330,15 @@ class ShiftOperator:
         # 1. split-fp16 hop: first choice on one GPU where the plan exists; results agree with the
         # exact-fp32 kernels to ~1e-7 of the operand scale.  SGP_TUNE=hop=exact keeps the fp32 matrix-core kernels.
         if force == "split" or (force is None and self.split_eligible(x, y, halo)):
-            splan = self.split_plan(x.device) if halo is None and x.shape[2] % 16 == 0 else None
+            splan = self.split_plan(x.device) if x.shape[2] % 16 == 0 else None
             if splan is not None:
                 if x_bound is None:
-                    x_bound = hip.abs_max(x)
+                    x_bound = hip.abs_max(x) if halo is None else max(hip.abs_max(x), hip.abs_max(halo))
                 if x_bound == 0.0:
                     x_bound = 1.0
                 if x_bound == x_bound and x_bound != float("inf"):
                     self.last_kernel = "spmm_split"
-                    hip.spmm_split(splan, x, y, x_bound)
+                    hip.spmm_split(splan, x, y, x_bound, halo=halo, n_own=self.num_nodes)
                     return y
             if force == "split":
                 raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")

@@ -108,7 +108,8 @@ SIGNATURES = {
     "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                     c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_abs_max_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p, c_p]),
-    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64,
+                                          c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p]),
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
@@ -320,7 +321,7 @@ def abs_max(x):
 
 
 @_on_device
-def spmm_split(plan, x, y, x_bound, t_chunk=0):
+def spmm_split(plan, x, y, x_bound, t_chunk=0, halo=None, n_own=None):
     """Split-fp16 hop (plan: sgp_amd.splitplan.SplitPlan on the device of ``x``).  ``x_bound`` >= max |x|
     (the caller's guarantee: reservoir states of tanh / self_norm layers are bounded by 1, a hop multiplies
     the bound by the operator's infinity norm); the scale puts it at 2^13..2^14 of the fp16 range."""
@@ -328,13 +329,18 @@ def spmm_split(plan, x, y, x_bound, t_chunk=0):
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
     yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
     if not (x_bound > 0 and math.isfinite(x_bound)):
         raise ValueError("spmm_split needs a finite positive bound on |x|")
     x_scale = 2.0 ** math.floor(math.log2(16384.0 / x_bound))
     _check(lib.sgp_spmm_split_f32(
         plan.hdr.data_ptr(), plan.rowid.data_ptr(), plan.ucol.data_ptr(), plan.afr.data_ptr(), plan.adr.data_ptr(),
         plan.n_tiles,
-        xp, xrs, xbs, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2],
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2],
         x_scale, plan.w_scale, t_chunk, _stream(x)), "sgp_spmm_split_f32")
 
 

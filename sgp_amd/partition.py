@@ -149,8 +149,8 @@ class HipOps:
         return hip.gather_nodes(x, index, out)
 
     @staticmethod
-    def propagate(op, x, y, halo):
-        return op.propagate(x, y, halo=halo)
+    def propagate(op, x, y, halo, x_bound=None):
+        return op.propagate(x, y, halo=halo, x_bound=x_bound)
 
     @staticmethod
     def node_sums(x):
@@ -247,6 +247,9 @@ class PartitionedSpatial:
         # communication stream) and per SpMM launch ("hop", on the compute stream)
         self.timeline = None
         self.node_order = None                     # set by make_partitioned_spatial
+        # infinity norms of the GLOBAL operators (one per direction): a hop multiplies the bound on |x| by it -- the
+        # same figure on every rank, whose halo rows are other ranks' results (set by make_partitioned_spatial)
+        self.norm_inf = None
 
     def num_blocks(self):
         return 1 + len(self.blocks) * self.k + (1 if self.global_attr else 0)
@@ -257,9 +260,20 @@ class PartitionedSpatial:
             self._xchg[key] = HaloExchange(self.blocks[d], self.group, self.ops)
         return self._xchg[key]
 
-    def _hops_serial(self, out, feat):
+    def _bound_after(self, bound, d):
+        if bound is None or self.norm_inf is None:
+            return None
+        return bound * max(self.norm_inf[d], 1e-30) * (1 + 1e-6)
+
+    def _propagate(self, blk, src, dst, halo, bound):
+        if bound is None:
+            return self.ops.propagate(blk.op, src, dst, halo)          # (test stand-ins take four arguments)
+        return self.ops.propagate(blk.op, src, dst, halo, bound)
+
+    def _hops_serial(self, out, feat, x_bound=None):
         for d, blk in enumerate(self.blocks):
             src = out[:, :, 0:feat]
+            bound = x_bound
             for h in range(self.k):
                 s = 1 + d * self.k + h
                 dst = out[:, :, s * feat:(s + 1) * feat]
@@ -271,14 +285,15 @@ class PartitionedSpatial:
                 halo = self._exchange(d, 0)(src) if self._dist else None
                 if timed:
                     c1.record()
-                self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
+                self._propagate(blk, src, dst, halo if blk.n_halo else None, bound)
+                bound = self._bound_after(bound, d)
                 if timed:
                     h1.record()
                     self.timeline.append(("comm", c0, c1))
                     self.timeline.append(("hop", c1, h1))
                 src = dst
 
-    def _hops_pipelined(self, out, feat):
+    def _hops_pipelined(self, out, feat, x_bound=None):
         T = out.shape[0]
         nc = min(self.n_chunks, T)
         cuts = [(T * j) // nc for j in range(nc + 1)]
@@ -290,6 +305,7 @@ class PartitionedSpatial:
         start.record(main)                          # block 0 (reservoir states) is complete
         for d, blk in enumerate(self.blocks):
             ready = [start] * nc                    # source slot of chunk j is written
+            bound = x_bound
             for h in range(self.k):
                 s_src = 0 if h == 0 else 1 + d * self.k + h - 1
                 s_dst = 1 + d * self.k + h
@@ -314,7 +330,7 @@ class PartitionedSpatial:
                     if timed:
                         h0 = torch.cuda.Event(enable_timing=True)
                         h0.record(main)
-                    self.ops.propagate(blk.op, src, dst, halo if blk.n_halo else None)
+                    self._propagate(blk, src, dst, halo if blk.n_halo else None, bound)
                     ev = torch.cuda.Event(enable_timing=timed)
                     ev.record(main)
                     done.append(ev)
@@ -322,17 +338,19 @@ class PartitionedSpatial:
                         self.timeline.append(("comm", c0, got))
                         self.timeline.append(("hop", h0, ev))
                 ready = done
+                bound = self._bound_after(bound, d)
         # the communication stream's buffers are reused by the next call: let it catch up
         comm.wait_stream(main)
 
-    def encode_into(self, out, feat, col_sums=None):
+    def encode_into(self, out, feat, col_sums=None, x_bound=None):
         """``col_sums`` [T, feat]: sums over the OWNED rows of slot 0 when the producer has them
         already (``Reservoir.encode_into``); they are all-reduced over the ranks like the sums this
-        method would otherwise compute from slot 0."""
+        method would otherwise compute from slot 0.  ``x_bound`` >= max |slot 0| over ALL ranks where the
+        caller knows it (bounded reservoir activations): the split-fp16 hop scales its operands by it."""
         if self._dist and out.is_cuda and self.n_chunks > 1 and out.shape[0] >= 8:
-            self._hops_pipelined(out, feat)
+            self._hops_pipelined(out, feat, x_bound)
         else:
-            self._hops_serial(out, feat)
+            self._hops_serial(out, feat, x_bound)
         if self.global_attr:
             p = self.num_blocks() - 1
             sums = col_sums if col_sums is not None else self.ops.node_sums(out[:, :, :feat])
@@ -357,13 +375,15 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     ``x[T, n_own, F]``, ``out[T, n_own, P * D_h]`` on the GPU."""
     T = x.shape[0]
     d_h = reservoir.output_size
+    # bounded activations bound the states on every rank alike (sgp_encoder.SGPEncoder._state_bound)
+    bound = 1.0 if getattr(reservoir, "mode", None) in ("tanh", "self_norm") and x.is_cuda else None
     pieces = spatial.n_chunks if pieces is None else pieces
     pieces = max(1, min(int(pieces), T // 8)) if x.is_cuda else 1
     want_sums = spatial.global_attr and x.is_cuda and reservoir.produces_col_sums(x)
     if pieces <= 1 or not x.is_cuda:
         sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
         reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
-        return spatial.encode_into(out, d_h, col_sums=sums)
+        return spatial.encode_into(out, d_h, col_sums=sums, x_bound=bound)
     if state is None:
         state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
                             dtype=torch.float32, device=x.device)
@@ -383,7 +403,7 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
         main.wait_event(ready)
         if sums is not None:
             sums.record_stream(main)
-        spatial.encode_into(out[t0:t1], d_h, col_sums=sums)
+        spatial.encode_into(out[t0:t1], d_h, col_sums=sums, x_bound=bound)
     for t in (x, out, state):
         t.record_stream(side)
     return out
@@ -436,4 +456,5 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
     spatial = PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
                                  n_chunks=n_chunks, force_collectives=force_collectives)
     spatial.node_order = node_order
+    spatial.norm_inf = [op.norm_inf() for op in ops_global]
     return spatial, bounds

@@ -145,7 +145,7 @@ if not torch.cuda.is_available():
         sp = op.split_plan(cpu)
         if sp is not None and feat %% 16 == 0:
             rc = lib.sgp_spmm_split_f32(P(sp.hdr), P(sp.rowid), P(sp.ucol), P(sp.afr), P(sp.adr), sp.n_tiles, P(x), feat, n * feat,
-                                        P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, 1.0, sp.w_scale, 0, None)
+                                        None, 0, 0, 0, P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, 1.0, sp.w_scale, 0, None)
             assert isinstance(rc, int) and rc != 0
             n_plans += 1
     # reservoir layer: every dispatch branch of the launch logic (split-J, exact deal + tail, even deal, stream)

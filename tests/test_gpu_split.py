@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from sgp_amd import graph, hip, synthetic
+from sgp_amd import graph, hip, partition, synthetic
 from test_gpu_parity import close, dense_ref
 
 pytestmark = pytest.mark.gpu
@@ -138,8 +138,8 @@ def test_split_time_chunks_and_run_to_run_determinism():
 
 
 def test_split_is_not_chosen_where_it_cannot_serve():
-    """Rows longer than a wave's column budget, halo blocks, widths that are not multiples of 16 and small
-    graphs keep the exact-fp32 kernels; ``force='split'`` says why it cannot."""
+    """Rows longer than a wave's column budget, widths that are not multiples of 16 and small graphs keep the
+    exact-fp32 kernels; ``force='split'`` says why it cannot."""
     n = 3000
     ei, ew, _ = synthetic.knn_graph(n, 30, seed=1)
     hub = torch.stack([torch.arange(400), torch.full((400,), 5)])      # row 5 gains 400 columns
@@ -202,3 +202,29 @@ def test_split_full_size_target_graph_properties():
     close(ya, yr, rtol=1e-5, atol=1e-5, fro=2e-6)
     op.propagate(torch.ones_like(x1), ya, force="split", x_bound=1.0)
     assert float((ya - 1).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_split_partitioned_blocks_with_halo(world):
+    """Local blocks of a node partition: halo rows arrive as a second source in the [rows, T, D] layout the
+    all_to_all produces (row stride T * D, batch stride D); the bound covers both sources."""
+    torch.manual_seed(world)
+    n, t, d = 7500, 6, 64                                           # blocks of >= 2048 rows: the split kernel's floor
+    ei, ew, _ = synthetic.knn_graph(n, 60, seed=9)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    x = torch.tanh(torch.randn(t, n, d))
+    ref = dense_ref(op, x)
+    bounds = partition.partition_bounds(n, world)
+    for r in range(world):
+        blk = partition.split_operator(op, bounds, r)
+        assert blk.n_halo > 0
+        xo = x[:, blk.lo:blk.hi].cuda().contiguous()
+        recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()
+        halo = recv.permute(1, 0, 2)
+        y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
+        blk.op.propagate(xo, y, halo=halo, x_bound=1.0)
+        assert blk.op.last_kernel == "spmm_split"                   # the default on a block of this size
+        close(y, ref[:, blk.lo:blk.hi])
+        y2 = torch.empty_like(y)
+        blk.op.propagate(xo, y2, halo=halo)                         # bound measured over both sources
+        close(y2, y, rtol=1e-6, atol=1e-6)

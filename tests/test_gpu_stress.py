@@ -27,8 +27,8 @@ def _cases():
     tgt = torch.repeat_interleave(torch.arange(n), deg)
     src = (tgt + torch.randint(-40, 41, tgt.shape)).clamp(0, n - 1)
     yield "ragged", graph.ShiftOperator.from_edges(torch.stack([src, tgt]), torch.rand(tgt.numel()) + .1, n), None, 67
-    ei, ew, _ = synthetic.knn_graph(2600, 60, seed=9)
-    full = graph.ShiftOperator.from_edges(ei, ew, 2600)
+    ei, ew, _ = synthetic.knn_graph(7000, 60, seed=9)
+    full = graph.ShiftOperator.from_edges(ei, ew, 7000)
     yield "halo", full, 1, 97
     ei, ew, _ = synthetic.knn_graph(4000, 30, seed=6)
     perm = torch.randperm(4000, generator=torch.Generator().manual_seed(1))
@@ -43,8 +43,6 @@ def test_hop_kernels_repeat_bit_for_bit(force):
         ref = dense_ref(op, x)
         halo = None
         if rank is not None:                                   # local block of a 3-way partition
-            if force == "split":
-                continue                                       # (no halo source in the split kernel)
             bounds = partition.partition_bounds(op.num_nodes, 3)
             blk = partition.split_operator(op, bounds, rank)
             assert blk.n_halo > 0

@@ -45,6 +45,14 @@ constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (f
 constexpr int NBUF = 3;                      // landing | being converted | being multiplied
 constexpr int HDR = 32;                      // ints per tile header: [8:16] rows of every wave, [16] staged rows U
 
+// ablation / timeline switches (SGP_TUNE=split_abl=..) exist only in builds with -DSGP_ABLATION (tools/build_variant.sh):
+// the product kernel carries none of their tests
+#ifdef SGP_ABLATION
+#define ABL(bit) ((a.mode & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 struct SplitArgs {
     const int* hdr; const int* rowid; const int* ucol; const h8* afr; const int* adr;
     int n_tiles, tiles_per_xcd;
@@ -97,16 +105,21 @@ static_assert(NCH >= 2, "the operand ring is primed with two chunks");
 static_assert(NLD <= NCH, "one staging piece per chunk of the MFMA phase");
 static_assert(NLD == 6, "wait_vm_n covers 0 .. 6 outstanding pieces");
 
-// v * s = hi + lo: hi by truncation (v_cvt_pkrtz: the remainder is then exact in fp32), lo rounded
+// v * s = hi + lo in 8 instructions per 4 values: hi = fp16(v * s), lo = fp16(v * s - hi) as ONE fused operation each
+// (v_fma_mixlo / mixhi_f16: fp32 fma of (fp32 v, fp32 s, fp16 half of a register), rounded once to fp16 into the low
+// / high half of the destination) -- the remainder of an 11-bit rounding of a 24-bit value is exact in the fma.
+// (hipcc's own sequence for the same split is 12: pk_mul, cvt_pkrtz, 2 cvt_f32_f16, pk_add, cvt_pk per pair.)
 __device__ __forceinline__ void split4(const f32x4 v, const float s, uint2& hi, uint2& lo) {
-    const float a0 = v[0] * s, a1 = v[1] * s, a2 = v[2] * s, a3 = v[3] * s;
-    const h2 h01 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a0, a1));
-    const h2 h23 = __builtin_bit_cast(h2, __builtin_amdgcn_cvt_pkrtz(a2, a3));
-    h2 l01, l23;
-    l01[0] = (_Float16)(a0 - (float)h01[0]); l01[1] = (_Float16)(a1 - (float)h01[1]);
-    l23[0] = (_Float16)(a2 - (float)h23[0]); l23[1] = (_Float16)(a3 - (float)h23[1]);
-    hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
-    lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
+    unsigned h01 = 0, h23 = 0, l01 = 0, l23 = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v[0]), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v[1]), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v[2]), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v[3]), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v[0]), "s"(s), "v"(h01));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v[1]), "s"(s), "v"(h01));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v[2]), "s"(s), "v"(h23));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v[3]), "s"(s), "v"(h23));
+    hi.x = h01; hi.y = h23; lo.x = l01; lo.y = l23;
 }
 
 template <bool HALO>
@@ -125,7 +138,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int src_tile = (a.mode & 16) ? xcd * a.tiles_per_xcd : tile;   // 16: every tile of an XCD stages the same rows
+    const int src_tile = ABL(16) ? xcd * a.tiles_per_xcd : tile;   // 16: every tile of an XCD stages the same rows
     const int nU = __builtin_amdgcn_readfirstlane(a.hdr[(size_t)src_tile * HDR + 2 * NW]);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         }
     };
     auto issue_dma = [&](int t, int sl, int buf) {
-        const float* xb = (a.mode & 64) ? a.X : a.X + (long long)t * a.xbs + sl * 16;   // 64: always step 0 (all L2 hits)
+        const float* xb = ABL(64) ? a.X : a.X + (long long)t * a.xbs + sl * 16;   // 64: always step 0 (all L2 hits)
         const float* xh = HALO ? a.XH + (long long)t * a.xhbs + sl * 16 : nullptr;
         const unsigned base = lds0 + buf * BUF + wave * 1024;
 #pragma unroll
@@ -229,10 +242,13 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     int t = t_begin, sl = 0, cur = 0;
     // measured (T = 512, target graph): all eight waves in the same order 17.6 ms per hop, the two waves of a SIMD in
     // opposite order (one multiplies while the other converts) 18.3 -- mode 128 selects the opposite order
-    const bool late = (wave >> 2) != 0 && (a.mode & 128);
+    // every wave multiplies first, then converts (three same-lease A/B runs: 17.7-18.1 ms per hop against 18.6-19.0 with
+    // the two waves of a SIMD in opposite order -- a conversion beside the partner's MFMAs takes twice as long);
+    // mode 128 selects the opposite order
+    const bool late = (wave >> 2) != 0 && ABL(128);
     f32x4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
     auto stamp = [&](int u, int k) {
-        if ((a.mode & 256) && blockIdx.x == 0 && lane == 0 && u >= 16 && u < 24)
+        if (ABL(256) && blockIdx.x == 0 && lane == 0 && u >= 16 && u < 24)
             a.dbg[((u - 16) * NW + wave) * 8 + k] = __builtin_amdgcn_s_memtime();
     };
     for (int u = 0; u < n_units; ++u) {
@@ -242,8 +258,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         const bool more2 = u + 2 < n_units;
         // the six pieces of unit u + 2 are requested one per chunk INSIDE the MFMA phase: a piece whose issue stalls on
         // a full memory queue then waits under matrix-core work that is already queued, not in front of it
-        const bool dma_now = more2 && !(a.mode & 1);
-        const float* xb2 = (a.mode & 64) ? a.X : a.X + (long long)dt * a.xbs + dsl * 16;
+        const bool dma_now = more2 && !ABL(1);
+        const float* xb2 = ABL(64) ? a.X : a.X + (long long)dt * a.xbs + dsl * 16;
         const float* xh2 = HALO ? a.XH + (long long)dt * a.xhbs + dsl * 16 : nullptr;
         const unsigned base2 = lds0 + nn * BUF + wave * 1024;
         if (dma_now) advance(dt, dsl);
@@ -252,18 +268,26 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         auto stage_next = [&]() {
             if (u + 1 < n_units) {
-                // the pieces of unit u + 1 were requested a whole unit ago; only the nld newest (unit u + 2) may stay in flight
-                // early waves (multiply first): only the nld pieces just requested (unit u + 2) may stay in flight;
-                // late waves convert BEFORE they request this unit's pieces: everything of theirs has to be back
-                if (dma_now && !late) wait_vm_n(nld); else wait_vm<0>();
-                if (!(a.mode & 8)) convert(nxt);
+                // the pieces of unit u + 1 were requested a whole unit ago; only the nld newest (unit u + 2, requested
+                // earlier in this unit by either kind of wave) may stay in flight
+                if (dma_now) wait_vm_n(nld); else wait_vm<0>();
+                if (!ABL(8)) convert(nxt);
             }
         };
-        // the two waves of a SIMD (w and w + 4) take the unit's two phases in opposite order: one multiplies while the
-        // other converts (both orders are legal: unit u was converted before the last barrier, unit u + 1 landed a unit ago)
-        if (late) stage_next();
+        // The two waves of a SIMD (w and w + 4) take the unit's two phases in opposite order, so one multiplies while
+        // the other converts (both orders are legal: unit u was converted before the last barrier, unit u + 1 landed a
+        // unit ago).  A late wave requests its pieces of unit u + 2 in front of its conversion, an early wave one per
+        // chunk inside its MFMA phase: either way they have a whole unit to land.
+        if (late) {
+            if (dma_now) {
+#pragma unroll
+                for (int i = 0; i < NLD; ++i)
+                    if (i < nld) piece(xoff[i], xb2, xh2, base2 + i * (NW * 1024));
+            }
+            stage_next();
+        }
         stamp(u, 2);
-        if (!(a.mode & 2)) {
+        if (!ABL(2)) {
             // operands of chunk c + 1 are requested before the MFMAs of chunk c issue
             const unsigned cbo = lds0 + cur * BUF;
             BOp b[3];                                         // two chunks in flight beside the one being multiplied
@@ -282,9 +306,9 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bl, acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][3], bh, acc1, 0, 0, 0);
-                if (c < NLD && dma_now && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024));
+                if (c < NLD && dma_now && !late && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024));
             }
-        } else if (dma_now) {
+        } else if (dma_now && !late) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
                 if (i < nld) piece(xoff[i], xb2, xh2, base2 + i * (NW * 1024));
@@ -292,16 +316,16 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         stamp(u, 3);
         if (!late) stage_next();
         stamp(u, 4);
-        if (!(a.mode & 4)) {
+        if (!ABL(4)) {
             f32x4 r0 = acc0 * a.inv_scale, r1 = acc1 * a.inv_scale;
             quad_transpose(r0);
             quad_transpose(r1);
             // an even slice waits for its odd neighbour: the two 64-byte halves of a 128-byte line leave together
-            if (!(sl & 1) && sl + 1 < a.nslice && !(a.mode & 32)) {
+            if (!(sl & 1) && sl + 1 < a.nslice && !ABL(32)) {
                 h0 = r0; h1 = r1;
             } else {
                 float* yb = a.Y + (long long)t * a.ybs + sl * 16;
-                if ((sl & 1) && !(a.mode & 32)) {
+                if ((sl & 1) && !ABL(32)) {
                     if (row_a >= 0) { *(f32x4*)(yb + yoff_a - 16) = h0; *(f32x4*)(yb + yoff_a) = r0; }
                     if (row_b >= 0) { *(f32x4*)(yb + yoff_b - 16) = h1; *(f32x4*)(yb + yoff_b) = r1; }
                 } else {
@@ -361,7 +385,11 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     }
     a.t_chunk = t_chunk;
     a.x_scale = x_scale; a.inv_scale = 1.f / (x_scale * w_scale);
+#ifdef SGP_ABLATION
     static const int abl = (int)sgp::tune("split_abl", 0);
+#else
+    constexpr int abl = 0;
+#endif
     a.mode = abl;
     a.dbg = nullptr;
     if (abl & 256) { if (hipMalloc(&a.dbg, 8 * NW * 8 * 8) != hipSuccess) return sgp::fail(SGP_EINVAL, "dbg alloc"); (void)hipMemset(a.dbg, 0, 8 * NW * 8 * 8); }

@@ -1,4 +1,5 @@
-"""Ablations of the split-fp16 hop on the target graph (SGP_TUNE=split_abl=.. is read once per process: one process per mode)."""
+"""Ablations of the split-fp16 hop on the target graph (needs an ablation build: tools/build_variant.sh abl -DSGP_ABLATION,
+SGP_AMD_LIB=tools/variants/abl/libsgp_amd.so) (SGP_TUNE=split_abl=.. is read once per process: one process per mode)."""
 import os, sys, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

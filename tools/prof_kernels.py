@@ -17,10 +17,11 @@ def main():
     if what in ("spmm", "both"):
         ei, ew, _ = synthetic.knn_graph(N, 100)
         op = graph.ShiftOperator.from_edges(ei, ew, N)
-        x = torch.randn(T, N, D, device="cuda")
+        x = torch.tanh(torch.randn(T, N, D, device="cuda"))
         y = torch.empty_like(x)
+        force = os.environ.get("SGP_FORCE", "split")
         for _ in range(3):
-            op.propagate(x, y, force=os.environ.get("SGP_FORCE", "split"))
+            op.propagate(x, y, force=force, x_bound=1.0 if force == "split" else None)
         torch.cuda.synchronize()
     if what in ("res", "both"):
         torch.manual_seed(0)

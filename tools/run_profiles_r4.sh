@@ -14,3 +14,9 @@ for w in ${@:-target}; do
   cp gpurun_out/prof_r4_$w/trace/*kernel_stats.csv $OUT/${w}_kernel_stats.csv 2>/dev/null
   echo "== $w"; cat $OUT/bench_${w}_line.json | head -c 700; echo
 done
+# SQ counters of the split-fp16 hop (T = 128) and its per-wave timeline
+if [ "${SQ:-0}" = 1 ]; then
+  SGP_FORCE=split bash tools/run_prof_sq.sh r4_split_sq 128
+  cp gpurun_out/prof_r4_split_sq/summary.txt $OUT/spmm_split_T128_sq_summary.txt 2>/dev/null
+  SGP_TUNE=split_abl=256 T=64 timeout 300 python tools/probe_split_abl.py 256 2>&1 | grep -A64 "spmm_split timeline" > $OUT/spmm_split_timeline.txt
+fi

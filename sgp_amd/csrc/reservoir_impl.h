@@ -272,7 +272,8 @@ constexpr int kLdsLimit = 160 * 1024;
 // The packed weights of a step are cut into blocks of 16 KB -- the fragments of all JT output
 // tiles for one k-block of W_hh (JT blocks), then for 4 input k-steps of W_ih (NKX/4 blocks) --
 // and the 4 waves fetch every block ONCE per workgroup by LDS-DMA (each wave 4 pieces of 1 KiB)
-// into a ring of 4 slots, two blocks ahead of the one being consumed; all 8 node tiles of the
+// into a ring of RING slots, AHEAD blocks ahead of the one being consumed (ring positions run on across the
+// steps: the number of blocks per step need not be a multiple of the ring length); all 8 node tiles of the
 // workgroup then read it with ds_read_b128.  Before, every wave pulled its own copy of the
 // 384 KB through L1/L2 each step (4x the traffic, one wave per SIMD to hide it).
 template <int I> struct IntC { static constexpr int value = I; };
@@ -290,12 +291,16 @@ template <int JT, int NKX, bool XVEC, bool OVEC>
 __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     static_assert(JT % 4 == 0 && NKX % 4 == 0, "stream kernel: 4 pieces per wave, 16-byte input fragments");
     constexpr int NT = 2;
+    // 4 slots / 2 ahead.  Round 4 measured 8 / 4 (128 KB): 58.4 against 57-58 ms per 256 steps at N = 100k -- the
+    // 37 % of parked wave cycles are not waits for weight blocks
+    constexpr int RING = 4, AHEAD = 2;
     constexpr int NB = JT + NKX / 4;                     // blocks per step
     constexpr int SLOT = JT * 1024;                      // bytes per block
     constexpr int PPW = JT / 4;                          // 1-KiB pieces of a block per wave
     static_assert(PPW == 4 || PPW == 2, "stream kernel: 8 or 16 output tiles");
+    static_assert((RING & (RING - 1)) == 0 && NB >= AHEAD && AHEAD < RING, "ring positions run on across the steps");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* bias_l = lds + 4 * SLOT / 4;                  // after the 4 ring slots
+    float* bias_l = lds + RING * SLOT / 4;               // after the ring slots
     for (int i = threadIdx.x; i < JT * 16; i += 256) bias_l[i] = a.wp[i];
     const float* wx = a.wp + JT * 16;
     const float* wh = wx + JT * NKX * 64;
@@ -339,12 +344,12 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PPW * wv) * 1024u);
     const float* wh_w = wh + (long long)(PPW * wv) * JT * 256;
     const float* wx_w = wx + (long long)(PPW * wv) * (NKX / 4) * 256;
-    auto fetch = [&](int b) {
+    auto fetch = [&](int b, int pos) {                   // block b of a step into ring position pos
         const float* hb = wh_w;
         const float* xb = wx_w;
         unsigned l0 = lds_w;
         asm volatile("" : "+s"(hb), "+s"(xb), "+s"(l0));
-        const unsigned slot = l0 + (unsigned)(b & 3) * SLOT;
+        const unsigned slot = l0 + (unsigned)(pos & (RING - 1)) * SLOT;
 #pragma unroll
         for (int pjt = 0; pjt < PPW; ++pjt) {
             const float* src = b < JT ? hb + (pjt * JT + b) * 256
@@ -354,8 +359,9 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // initial-state loads retired (see above)
     __syncthreads();
-    fetch(0);
-    fetch(1);
+#pragma unroll
+    for (int b = 0; b < AHEAD; ++b) fetch(b, b);
+    int cnt = 0;                                         // blocks consumed so far (ring position of the next one)
 
     for (int t = 0; t < a.T; ++t) {
         float xr[NT][NKX];
@@ -387,15 +393,15 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
         // loop here turns both arrays into scratch memory)
         static_for<0, NB>([&](auto bc) {
             constexpr int b = decltype(bc)::value;
-            // two blocks ahead (the sequence repeats every step); slot (b + 2) & 3 was last read
-            // as block b - 2, which every wave finished before it passed the previous barrier
-            fetch((b + 2) % NB);
-            // block b: 4 pieces issued two fetches ago.  Once per step everything is drained
+            // AHEAD blocks ahead (the sequence repeats every step, the ring positions run on): position cnt + AHEAD
+            // was last read RING - AHEAD blocks ago, which every wave finished before it passed an earlier barrier
+            fetch((b + AHEAD) % NB, cnt + AHEAD);
+            // block b: its PPW pieces were issued AHEAD fetches ago.  Once per step everything is drained
             // (the input-row loads and state stores of the step boundary share the counter).
             if constexpr (b == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            else if constexpr (PPW == 4) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            const float* slot = lds + (b & 3) * (SLOT / 4);
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(AHEAD * PPW) : "memory");
+            const float* slot = lds + (cnt & (RING - 1)) * (SLOT / 4);
+            ++cnt;
 #pragma unroll
             for (int jt = 0; jt < JT; ++jt) {
                 const f32x4 wf = *reinterpret_cast<const f32x4*>(slot + (jt * 64 + lane) * 4);
@@ -486,7 +492,7 @@ int launch_stream(ResArgs a, hipStream_t s) {
     else tail_wgs = (rest + 3) / 4;
     a.tiles_per_wave = full;
     void (*kern)(ResArgs) = reservoir_layer_stream<JT, NKX, true, true>;
-    const int bytes = 4 * JT * 1024 + JT * 16 * 4;
+    const int bytes = 4 * JT * 1024 + JT * 16 * 4;           // RING slots + bias
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));

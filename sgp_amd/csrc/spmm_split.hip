@@ -39,8 +39,11 @@ constexpr int NW = 8;                        // waves per workgroup
 #define SGP_SPLIT_NCH 9
 #endif
 constexpr int NCH = SGP_SPLIT_NCH;           // resident 32-column chunks per wave (experiment builds: -DSGP_SPLIT_NCH=..)
-constexpr int SMAX = 768;                    // staged rows per tile
-constexpr int NLD = SMAX / (16 * NW);        // 6 LDS-DMA instructions per wave and unit (16 rows each)
+#ifndef SGP_SPLIT_SMAX
+#define SGP_SPLIT_SMAX 768
+#endif
+constexpr int SMAX = SGP_SPLIT_SMAX;         // staged rows per tile (3 x 64 x SMAX bytes of LDS: at most 832)
+constexpr int NLD = (SMAX + 16 * NW - 1) / (16 * NW);   // LDS-DMA instructions per wave and unit (16 rows each)
 constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
 constexpr int NBUF = 3;                      // landing | being converted | being multiplied
 constexpr int HDR = 32;                      // ints per tile header: [8:16] rows of every wave, [16] staged rows U
@@ -98,12 +101,12 @@ __device__ __forceinline__ void wait_vm_n(int n) {       // n is wave-uniform, 0
     switch (n) {
         case 0: wait_vm<0>(); break; case 1: wait_vm<1>(); break; case 2: wait_vm<2>(); break;
         case 3: wait_vm<3>(); break; case 4: wait_vm<4>(); break; case 5: wait_vm<5>(); break;
-        default: wait_vm<6>(); break;
+        case 6: wait_vm<6>(); break; default: wait_vm<7>(); break;
     }
 }
 static_assert(NCH >= 2, "the operand ring is primed with two chunks");
 static_assert(NLD <= NCH, "one staging piece per chunk of the MFMA phase");
-static_assert(NLD == 6, "wait_vm_n covers 0 .. 6 outstanding pieces");
+static_assert(NLD <= 7 && NBUF * BUF <= 160 * 1024, "wait_vm_n covers 0 .. 7 outstanding pieces; three buffers in 160 KB");
 
 // v * s = hi + lo in 8 instructions per 4 values: hi = fp16(v * s), lo = fp16(v * s - hi) as ONE fused operation each
 // (v_fma_mixlo / mixhi_f16: fp32 fma of (fp32 v, fp32 s, fp16 half of a register), rounded once to fp16 into the low

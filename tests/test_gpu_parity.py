@@ -277,12 +277,14 @@ def test_fused_multi_layer_reservoir(n, f, r, L, act):
 
 
 @pytest.mark.parametrize("act,f,r", [("tanh", 128, 256), ("relu", 128, 256), ("self_norm", 128, 256),
-                                     ("tanh", 256, 128)])
+                                     ("tanh", 256, 128), ("tanh", 16, 256), ("tanh", 32, 256), ("tanh", 64, 256)])
 def test_reservoir_wide_streamed_weights(act, f, r):
     """C5's layer shape (F = 128, R = 256: 384 KB of weights, more than the LDS) at a node count
     that takes the kernel which streams the weights through LDS once per workgroup (full
     workgroups with two node tiles per wave AND the half-filled tail ones), against the oracle;
-    then the same sequence in two time chunks with the state carried on the device."""
+    then the same sequence in two time chunks with the state carried on the device.  F = 16 / 32 at
+    R = 256 make 17 / 18 weight blocks per step -- not a multiple of the ring length: the ring positions
+    must run on across the steps (round 4; before, block 16 was overwritten in its slot before it was read)."""
     torch.manual_seed(5)
     n, t = 2048 * 16 + 16 * 37 + 5, 10
     res = sgp_amd.Reservoir(f, r, num_layers=1, leaking_rate=0.8, spectral_radius=0.9, density=0.7,
@@ -807,7 +809,17 @@ def test_decoder_dropout_mask_is_shared_by_forward_and_backward():
     gw = torch.einsum("rgo,rgi->goi", m.double(), xg.double()).reshape(enc.weight.shape)
     assert O.rel_fro(enc.weight.grad.cpu().double(), gw.cpu()) <= 1e-5
     with pytest.raises(ValueError):
-        SGPInputEncoder(f, order, hidden, dropout=1.0)
+        SGPInputEncoder(f, order, hidden, dropout=1.5)
+    # p = 1 is legal, as for nn.Dropout: everything is dropped in training mode, gradients are zero
+    full = SGPInputEncoder(f, order, hidden, activation=None, dropout=1.0).cuda()
+    full.train()
+    z = full(x)
+    assert float(z.abs().max()) == 0.0
+    z.sum().backward()
+    assert float(full.weight.grad.abs().max()) == 0.0 and float(full.bias.grad.abs().max()) == 0.0
+    full.eval()
+    with torch.no_grad():
+        assert float(full(x).abs().max()) > 0.0
 
 
 @pytest.mark.parametrize("name", golden_files("g9_onthefly_"))

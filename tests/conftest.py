@@ -21,3 +21,14 @@ def golden_files(prefix):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    """The GPU box has 256 hardware threads; the CPU oracle's per-step operands are small, and a pool that wide
+    spends the time of a long recurrence in dispatch (C2 at T = 52 116: 294 s against 19 s).  16 threads serve both
+    the small recurrences and the N = 100 000 sparse products of the tests."""
+    import torch
+    if torch.get_num_threads() > 16:
+        torch.set_num_threads(16)
+    yield

@@ -69,9 +69,15 @@ def test_baseline_configs_at_their_full_T(cfg):
     out = enc.encode_device(x.cuda(), ops, state=state)
     assert out.shape == (t, n, enc.output_size)
     tail = out[-16:].cpu()
-    # fp64 oracle: reservoir over all T steps, propagation on the last 16
+    # fp64 oracle: reservoir over all T steps, propagation on the last 16.  (Few threads: the per-step operands are
+    # small, and a 256-thread pool spends the time of ~50 000 steps in dispatch.)
     layers = layers_of(enc.reservoir)
-    h = O.reservoir_forward(x, layers, dtype=torch.float64)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 8))
+    try:
+        h = O.reservoir_forward(x, layers, dtype=torch.float64)
+    finally:
+        torch.set_num_threads(threads)
     cops = O.shift_operators_csr(ei, ew, n, bidirectional=kw["bidirectional"])
     cops = [a.to(torch.float64) for a in cops]
     blocks = [h[-16:]]

@@ -402,22 +402,33 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
             else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(AHEAD * PPW) : "memory");
             const float* slot = lds + (cnt & (RING - 1)) * (SLOT / 4);
             ++cnt;
+            // Round 4: the weight fragment of output tile jt + 1 is requested BEFORE the MFMAs of tile jt issue, and
+            // the "second node tile present" test is made once per block instead of once per MFMA pair.  Before,
+            // every tile's 8 MFMAs (256 cycles) sat behind a ds_read_b128 + lgkmcnt(0) issued right in front of them
+            // and four scalar branches: SQ_WAIT_ANY 37 % of the wave cycles.
+            auto run = [&](auto two_c) {
+                constexpr bool TWO = decltype(two_c)::value;
+                f32x4 wf = *reinterpret_cast<const f32x4*>(slot + lane * 4);
 #pragma unroll
-            for (int jt = 0; jt < JT; ++jt) {
-                const f32x4 wf = *reinterpret_cast<const f32x4*>(slot + (jt * 64 + lane) * 4);
+                for (int jt = 0; jt < JT; ++jt) {
+                    f32x4 wn = wf;
+                    if (jt + 1 < JT) wn = *reinterpret_cast<const f32x4*>(slot + ((jt + 1) * 64 + lane) * 4);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    if constexpr (b < JT) {
-                        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[0][b][s], acc[0][jt], 0, 0, 0);
-                        if (two)
-                            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[1][b][s], acc[1][jt], 0, 0, 0);
-                    } else {
-                        acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[0][4 * (b - JT) + s], acc[0][jt], 0, 0, 0);
-                        if (two)
-                            acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[1][4 * (b - JT) + s], acc[1][jt], 0, 0, 0);
+                    for (int s = 0; s < 4; ++s) {
+                        if constexpr (b < JT) {
+                            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[0][b][s], acc[0][jt], 0, 0, 0);
+                            if constexpr (TWO)
+                                acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], h[1][b][s], acc[1][jt], 0, 0, 0);
+                        } else {
+                            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[0][4 * (b - JT) + s], acc[0][jt], 0, 0, 0);
+                            if constexpr (TWO)
+                                acc[1][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s], xr[1][4 * (b - JT) + s], acc[1][jt], 0, 0, 0);
+                        }
                     }
+                    wf = wn;
                 }
-            }
+            };
+            if (two) run(IntC<1>{}); else run(IntC<0>{});
         });
 #pragma unroll
         for (int i = 0; i < NT; ++i) {

@@ -37,6 +37,8 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
     x, _ = dataset.get_tensors(['data'] + exo_keys, preprocess=True, cat_dim=-1)
     encoder = encoder_class(**encoder_kwargs)
 
+    if shard_steps is not None and (save_path is None or return_device):
+        raise ValueError("shard_steps needs save_path (a directory) and a host embedding")
     started = time()
     if return_device:                 # every encoder answers on the device of its input
         from . import hip
@@ -44,8 +46,6 @@ def encode_dataset(dataset, encoder_class, encoder_kwargs, encode_exogenous=True
         x = x.cuda()
     from .multigpu import resolve_gpus
     if shard_steps is not None:
-        if save_path is None or return_device:
-            raise ValueError("shard_steps needs save_path (a directory) and a host embedding")
         embedding = encoder(x, edge_index=dataset.edge_index, edge_weight=dataset.edge_weight, gpus=gpus,
                             shard_dir=str(save_path), shard_steps=int(shard_steps))
     elif resolve_gpus(gpus) > 1:

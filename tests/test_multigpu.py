@@ -48,6 +48,43 @@ def test_gpus_argument_is_rejected_where_it_cannot_be_served():
         enc(torch.randn(4, 2, 3), ei, None, gpus=2, return_device=True)
 
 
+def test_sharded_embedding_reads_time_and_node_shards_back(tmp_path):
+    """ShardedEmbedding over shard files as the one-GPU path (time shards of all nodes) and the ranks of the
+    partitioned path (time x node-block shards, rows in any order) write them: every time range comes back in the
+    original node order."""
+    from sgp_amd.datasets import ShardedEmbedding
+    t, n, d = 23, 17, 5
+    full = torch.randn(t, n, d)
+    paths = []
+    for t0 in range(0, t, 8):                                   # time shards
+        p = str(tmp_path / f"a_{t0}.pt")
+        torch.save(dict(t0=t0, steps=min(8, t - t0), rows=None, embedding=full[t0:t0 + 8].clone()), p)
+        paths.append(p)
+    ShardedEmbedding.write_index(str(tmp_path), paths, (t, n, d))
+    emb = ShardedEmbedding.from_dir(str(tmp_path))
+    assert emb.shape == (t, n, d) and len(emb) == t
+    assert torch.equal(emb.load_steps(0, t), full) and torch.equal(emb.load_steps(5, 19), full[5:19])
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    paths = []
+    for r, rows in enumerate((perm[:9], perm[9:])):             # two ranks, scattered node blocks, two time chunks
+        for t0 in (0, 12):
+            p = str(tmp_path / f"b_{r}_{t0}.pt")
+            steps = 12 if t0 == 0 else t - 12
+            torch.save(dict(t0=t0, steps=steps, rank=r, rows=rows, embedding=full[t0:t0 + steps][:, rows].clone()), p)
+            paths.append(p)
+    emb = ShardedEmbedding(paths, t, n, d)
+    assert torch.equal(emb.load_steps(0, t), full) and torch.equal(emb.load_steps(11, 13), full[11:13])
+
+
+def test_shard_steps_needs_a_directory_and_a_host_embedding():
+    from test_host_logic import FakeDataset, StubEncoder
+    ds = FakeDataset(torch.randn(6, 4, 1), torch.randn(6, 2), torch.tensor([[0, 1], [1, 2]]), None)
+    with pytest.raises(ValueError):
+        sgp_amd.encode_dataset(ds, StubEncoder, dict(input_size=3), shard_steps=4)                 # no save_path
+    with pytest.raises(ValueError):
+        sgp_amd.encode_dataset(ds, StubEncoder, dict(input_size=3), shard_steps=4, save_path="x", return_device=True)
+
+
 # ------------------------------------------------------------------ GPU
 def _encoder(seed=3, **kw):
     torch.manual_seed(seed)

@@ -490,6 +490,213 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
     }
 }
 
+// ---- 8-wave form (round 4): one node tile per wave, two waves per SIMD --------------------------------------
+template <int JT, int NKX, bool XVEC, bool OVEC>
+__global__ __launch_bounds__(512, 2) void reservoir_layer_stream8(ResArgs a) {
+    static_assert(JT % 8 == 0 && NKX % 4 == 0, "stream8 kernel: JT / 8 pieces per wave, 16-byte input fragments");
+    constexpr int NT = 1;
+    // 4 slots / 2 ahead.  Round 4 measured 8 / 4 (128 KB): 58.4 against 57-58 ms per 256 steps at N = 100k -- the
+    // 37 % of parked wave cycles are not waits for weight blocks
+    constexpr int RING = 4, AHEAD = 2;
+    constexpr int NB = JT + NKX / 4;                     // blocks per step
+    constexpr int SLOT = JT * 1024;                      // bytes per block
+    constexpr int PPW = JT / 8;                          // 1-KiB pieces of a block per wave
+    static_assert(PPW == 2 || PPW == 1, "stream8 kernel: 8 or 16 output tiles");
+    static_assert((RING & (RING - 1)) == 0 && NB >= AHEAD && AHEAD < RING, "ring positions run on across the steps");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bias_l = lds + RING * SLOT / 4;               // after the ring slots
+    for (int i = threadIdx.x; i < JT * 16; i += 512) bias_l[i] = a.wp[i];
+    const float* wx = a.wp + JT * 16;
+    const float* wh = wx + JT * NKX * 64;
+
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // tile assignment (host: launch_stream): one tile per wave; full workgroups own 8 tiles (two waves per SIMD:
+    // one multiplies while the other requests weight pieces, loads its input row or evaluates tanh), the tail
+    // ones 4 (waves 0-3, one per SIMD; waves 4-7 only carry their share of the weight pieces)
+    const int full = a.tiles_per_wave;                   // number of workgroups with 8 tiles
+    int tile0, tile1;
+    if ((int)blockIdx.x < full) { tile0 = (int)blockIdx.x * 8 + wv; tile1 = tile0 + 1; }
+    else { tile0 = full * 8 + ((int)blockIdx.x - full) * 4 + wv; tile1 = wv < 4 ? tile0 + 1 : tile0; }
+    tile1 = min(tile1, a.n_tiles);
+    const bool busy = tile0 < tile1;                     // wave-uniform: this wave owns a tile
+
+    int node[NT];
+    bool ok[NT];
+    f32x4 h[NT][JT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        node[i] = (tile0 + i) * 16 + n_in;
+        ok[i] = (tile0 + i) < tile1 && node[i] < a.N;
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            float hv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (a.h_state && ok[i]) {
+                const int j0 = 16 * jt + 4 * q;
+                const float* hp = a.h_state + (long long)node[i] * a.R + j0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    hv[r] = hp[r];
+            }
+            h[i][jt] = f32x4{hv[0], hv[1], hv[2], hv[3]};
+        }
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned voff = (unsigned)lane * 16u;
+    // block b of a step -> the PPW pieces of this wave (jt = PPW wv .. PPW wv + PPW - 1).  The two base
+    // pointers are re-laundered every call so that the compiler forms the 96 piece addresses of a
+    // step with scalar adds on the spot instead of keeping them all in (spilled) SGPRs.
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PPW * wv) * 1024u);
+    const float* wh_w = wh + (long long)(PPW * wv) * JT * 256;
+    const float* wx_w = wx + (long long)(PPW * wv) * (NKX / 4) * 256;
+    auto fetch = [&](int b, int pos) {                   // block b of a step into ring position pos
+        const float* hb = wh_w;
+        const float* xb = wx_w;
+        unsigned l0 = lds_w;
+        asm volatile("" : "+s"(hb), "+s"(xb), "+s"(l0));
+        const unsigned slot = l0 + (unsigned)(pos & (RING - 1)) * SLOT;
+#pragma unroll
+        for (int pjt = 0; pjt < PPW; ++pjt) {
+            const float* src = b < JT ? hb + (pjt * JT + b) * 256
+                                      : xb + (pjt * (NKX / 4) + (b - JT)) * 256;
+            res_dma16(src, voff, slot + (unsigned)pjt * 1024u);
+        }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // initial-state loads retired (see above)
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < AHEAD; ++b) fetch(b, b);
+    int cnt = 0;                                         // blocks consumed so far (ring position of the next one)
+
+    for (int t = 0; t < a.T; ++t) {
+        float xr[NT][NKX];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float* xp = a.x + (long long)t * a.xss + (long long)node[i] * a.xrs + q * NKX;
+            if constexpr (XVEC) {
+#pragma unroll
+                for (int k4 = 0; k4 < NKX / 4; ++k4) {
+                    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ok[i]) v = *reinterpret_cast<const f32x4*>(xp + 4 * k4);   // F == 4 NKX (host check)
+                    xr[i][4 * k4 + 0] = v.x; xr[i][4 * k4 + 1] = v.y;
+                    xr[i][4 * k4 + 2] = v.z; xr[i][4 * k4 + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks)
+                    xr[i][ks] = ok[i] ? xp[ks] : 0.f;
+            }
+        }
+        f32x4 acc[NT][JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias_l + jt * 16 + q * 4);
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i][jt] = bv;
+        }
+        // (compile-time block index: h[.][b] and xr[.][ks] must be register names, a runtime
+        // loop here turns both arrays into scratch memory)
+        static_for<0, NB>([&](auto bc) {
+            constexpr int b = decltype(bc)::value;
+            // AHEAD blocks ahead (the sequence repeats every step, the ring positions run on): position cnt + AHEAD
+            // was last read RING - AHEAD blocks ago, which every wave finished before it passed an earlier barrier
+            fetch((b + AHEAD) % NB, cnt + AHEAD);
+            // block b: its PPW pieces were issued AHEAD fetches ago.  Once per step everything is drained
+            // (the input-row loads and state stores of the step boundary share the counter).
+            if constexpr (b == 0) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(AHEAD * PPW) : "memory");
+            const float* slot = lds + (cnt & (RING - 1)) * (SLOT / 4);
+            ++cnt;
+            // Round 4: the weight fragment of output tile jt + 1 is requested BEFORE the MFMAs of tile jt issue, and
+            // the "second node tile present" test is made once per block instead of once per MFMA pair.  Before,
+            // every tile's 8 MFMAs (256 cycles) sat behind a ds_read_b128 + lgkmcnt(0) issued right in front of them
+            // and four scalar branches: SQ_WAIT_ANY 37 % of the wave cycles.
+            if (busy) {
+                // two output tiles at a time: their MFMAs alternate, so a tile's next MFMA finds its accumulator ready
+                f32x4 wa = *reinterpret_cast<const f32x4*>(slot + lane * 4);
+                f32x4 wb = *reinterpret_cast<const f32x4*>(slot + (64 + lane) * 4);
+#pragma unroll
+                for (int jt = 0; jt < JT; jt += 2) {
+                    f32x4 na = wa, nb = wb;
+                    if (jt + 2 < JT) {
+                        na = *reinterpret_cast<const f32x4*>(slot + ((jt + 2) * 64 + lane) * 4);
+                        nb = *reinterpret_cast<const f32x4*>(slot + ((jt + 3) * 64 + lane) * 4);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        if constexpr (b < JT) {
+                            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], h[0][b][s], acc[0][jt], 0, 0, 0);
+                            acc[0][jt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s], h[0][b][s], acc[0][jt + 1], 0, 0, 0);
+                        } else {
+                            acc[0][jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[s], xr[0][4 * (b - JT) + s], acc[0][jt], 0, 0, 0);
+                            acc[0][jt + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb[s], xr[0][4 * (b - JT) + s], acc[0][jt + 1], 0, 0, 0);
+                        }
+                    }
+                    wa = na; wb = nb;
+                }
+            }
+        });
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            if (!busy) continue;
+            if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
+            } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+            } else if (a.act == SGP_ACT_SELF_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss = fmaf(acc[i][jt][r], acc[i][jt][r], ss);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] *= inv;
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha)
+                                                        : leak(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha);
+                const int j0 = 16 * jt + 4 * q;
+                if (ok[i]) {                                  // R == 16 JT (host check)
+                    float* op = a.out + (long long)t * a.oss + (long long)node[i] * a.ors + j0;
+                    if constexpr (OVEC) {
+                        *reinterpret_cast<f32x4*>(op) = h[i][jt];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) op[r] = h[i][jt][r];
+                    }
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the two blocks fetched ahead of the end
+    if (a.h_state) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) {
+                const int j0 = 16 * jt + 4 * q;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ok[i]) a.h_state[(long long)node[i] * a.R + j0 + r] = h[i][jt][r];
+            }
+    }
+}
+
 template <int JT, int NKX>
 int launch_stream(ResArgs a, hipStream_t s) {
     a.n_tiles = (a.N + 15) / 16;
@@ -502,12 +709,14 @@ int launch_stream(ResArgs a, hipStream_t s) {
     if (rest > 1024) { full += (rest + 7) / 8; tail_wgs = 0; }
     else tail_wgs = (rest + 3) / 4;
     a.tiles_per_wave = full;
-    void (*kern)(ResArgs) = reservoir_layer_stream<JT, NKX, true, true>;
+    // 8 waves x 1 tile (two waves per SIMD) unless SGP_TUNE=res_stream8=0 asks for round 3's 4 waves x 2 tiles
+    static const int eight = (int)sgp::tune("res_stream8", 1);
+    void (*kern)(ResArgs) = eight ? reservoir_layer_stream8<JT, NKX, true, true> : reservoir_layer_stream<JT, NKX, true, true>;
     const int bytes = 4 * JT * 1024 + JT * 16 * 4;           // RING slots + bias
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(full + tail_wgs), dim3(256), (size_t)bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(full + tail_wgs), dim3(eight ? 512 : 256), (size_t)bytes, s, a);
     return sgp::check_launch("reservoir_layer_stream");
 }
 

@@ -20,7 +20,7 @@ Library (integers)
     split_abl=0             ablation bits of sgp_spmm_split_f32, -DSGP_ABLATION builds only (1 no loads, 2 no MFMAs, 4 no stores, 8 no
                             conversion, 16 shared rows per XCD, 32 unpaired stores, 64 always step 0,
                             128 the two waves of a SIMD take the phases in opposite order, 256 per-wave timeline of workgroup 0)
-    gesn_persistent=1, gesn_dbg=0, stack_debug=0, res_splitj_max, res_tail=1   reservoir / DynGESN experiments
+    gesn_persistent=1, gesn_dbg=0, stack_debug=0, res_splitj_max, res_tail=1, res_stream8=1   reservoir / DynGESN experiments
 """
 import os
 

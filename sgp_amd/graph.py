@@ -464,7 +464,7 @@ class TilePlan:
     gw: Optional[torch.Tensor] = None       # float32 [n_quads, 4 classes, 4 rows, 4]
     max_tile_quads: int = 0
     rowmap: Optional[torch.Tensor] = None   # int32 [64 * n_tiles] output row of every (tile, slot), -1 = none
-    pipe: Optional[dict] = None             # two-phase stream of sgp_spmm_pipe_f32 (build_phase_stream)
+    pipe: Optional[dict] = None             # two-phase row-group stream of sgp_spmm_res_f32 / _mix (build_phase_stream)
     reordered: bool = False                 # tiles follow locality_order, not the row numbering
 
     def to(self, device):
@@ -527,7 +527,7 @@ def refine_tiles(rowptr, col, trow, max_union, min_rows=8):
         trow = np.unique(np.concatenate([trow, mids]))
 
 
-GROUP_ROWS = 4          # rows per wave in sgp_spmm_mfma_f32
+GROUP_ROWS = 4          # rows per group of the exact-fp32 row-group kernels (sgp_spmm_res_f32 / _mix)
 GROUPS_PER_TILE = 16    # 16 waves per workgroup -> tiles of at most 64 rows
 
 
@@ -605,7 +605,8 @@ def balance_groups_over_simds(trow, lcol, row_of_edge, slot_of_row):
 
 
 def build_group_stream(trow, lcol, row_of_edge, val, slot_of_row=None):
-    """Row-group stream of ``sgp_spmm_mfma_f32`` (include/sgp_amd.h).  Slot s of a tile belongs
+    """Single-range row-group stream (round 1's layout; kept because ``group_fill`` and the row clustering of the
+    two-phase stream are derived from it).  Slot s of a tile belongs
     to group s // 4; for every group: the sorted union of its rows' local column indices,
     dealt round-robin to 4 classes (position p -> super-step p // 4, class p % 4), stored 4
     super-steps per "quad" as weights ``gw[quad][class][row][4]`` and LDS byte offsets of the
@@ -711,7 +712,7 @@ def place_groups_two_phase(qa, qb):
 
 def build_phase_stream(trow, uptr, ucol, lcol, row_of_edge, val, slot_of_row=None, rebalance=True,
                        mode="parity"):
-    """Row-group stream of ``sgp_spmm_pipe_f32`` (include/sgp_amd.h): as ``build_group_stream`` but
+    """Two-phase row-group stream of ``sgp_spmm_res_f32`` / ``sgp_spmm_mix_f32`` (include/sgp_amd.h): as ``build_group_stream`` but
     every tile's distinct-column list is cut into two segments A | B that the kernel stages
     alternately, and every group's quads are stored A-part first: ``gptr[2 g] .. gptr[2 g + 1]`` =
     quads that only touch segment A, ``gptr[2 g + 1] .. gptr[2 g + 2]`` = quads of segment B.

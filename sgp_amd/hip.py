@@ -267,7 +267,7 @@ def spmm_tiled(plan, x, y, halo=None, n_own=None):
 
 @_on_device
 def spmm_res(plan, x, y, halo=None, n_own=None):
-    """Register-resident two-phase row-group product (same plan and results as spmm_pipe)."""
+    """Register-resident two-phase row-group product, exact fp32 (plan: ``TilePlan.pipe``)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
     yp, yrs, ybs = _view3(y, "y")

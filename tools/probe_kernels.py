@@ -31,7 +31,7 @@ def main():
         T = N_T
         x = torch.randn(T, N, D, device="cuda"); y = torch.empty_like(x)
         bytes_hop = 2 * N * T * D * 4 + op.nnz() * 8 + (N + 1) * 4
-    for force in os.environ.get("SGP_PROBE", "pipe,mfma,tiled,csr").split(","):
+    for force in os.environ.get("SGP_PROBE", "split,mix,res,tiled,csr").split(","):
         ms = timeit(lambda: op.propagate(x, y, force=force))
         print(f"spmm {force}: {ms:.2f} ms  {bytes_hop / ms / 1e6:.1f} GB/s  frac {bytes_hop / ms / 1e6 / 8000:.3f}", flush=True)
     if only_spmm:

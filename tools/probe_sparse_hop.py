@@ -23,7 +23,7 @@ for (N, E, D, T) in [(325, 2369, 128, 16384), (207, 1515, 64, 34272)]:
     plan = op.tile_plan(D, x.device)
     print(f"N={N} E={E} D={D} T={T}: tiles {plan.n_tiles} fill {plan.pipe['fill'] if plan.pipe else None}", flush=True)
     op.propagate(x, y0, force="csr")
-    for force in ("tiled", "res", "pipe", "mfma", "csr"):
+    for force in ("tiled", "res", "mix", "csr"):
         try:
             ms = timeit(lambda: op.propagate(x, y, force=force))
             err = float((y - y0).abs().max())

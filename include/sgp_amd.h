@@ -60,6 +60,11 @@ const char* sgp_last_error(void);
 /* Name of the gfx target the device code was compiled for ("gfx950"). */
 const char* sgp_build_arch(void);
 
+/* The library's view of the ONE debug / tuning hook, the environment variable SGP_TUNE = "key=value,key=value"
+ * (keys: sgp_amd/tune.py): the integer value of `key`, `dflt` when the variable or the key is absent.  Most keys
+ * are read once per process by the kernel launchers; this entry parses the variable anew on every call. */
+int64_t sgp_tune_value(const char* key, int64_t dflt);
+
 /* ------------------------------------------------------------------ SpMM ---
  * Y[b, i, 0:feat] = sum_{e in [rowptr[i], rowptr[i+1])} val[e] * X[b, col[e], 0:feat]
  * for b in [0, batch), i in [0, n_rows).  X and Y may alias the same

@@ -55,6 +55,7 @@ extern "C" {
 int sgp_abi_version(void) { return SGP_ABI_VERSION; }
 const char* sgp_last_error(void) { return sgp::err_buf(); }
 const char* sgp_build_arch(void) { return "gfx950"; }
+int64_t sgp_tune_value(const char* key, int64_t dflt) { return key ? (int64_t)sgp::tune(key, (long)dflt) : dflt; }
 
 int sgp_event_create(void** ev) {
     SGP_REQUIRE(ev != nullptr, "sgp_event_create: null out pointer");

@@ -25,6 +25,7 @@ SIGNATURES = {
     "sgp_abi_version": (ctypes.c_int, []),
     "sgp_last_error": (ctypes.c_char_p, []),
     "sgp_build_arch": (ctypes.c_char_p, []),
+    "sgp_tune_value": (c_i64, [ctypes.c_char_p, c_i64]),
     "sgp_spmm_csr_f32": (ctypes.c_int, [c_p, c_p, c_p,
                                         c_p, c_i64, c_i64,
                                         c_p, c_i64, c_i64, c_i32,

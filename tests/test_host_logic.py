@@ -447,3 +447,19 @@ def test_equal_cost_tiles_cover_the_rows_and_respect_the_limits():
     # the stream still reproduces the operator: every edge weight appears exactly once
     assert abs(float(eq.pipe["gw"].double().sum()) - float(op.val.double().sum())) < 1e-3 * n
     assert sorted(eq.pipe["rowmap"][eq.pipe["rowmap"] >= 0].tolist()) == list(range(n))
+
+
+def test_sgp_tune_is_one_hook_read_alike_by_python_and_the_library(monkeypatch):
+    """SGP_TUNE="key=value,..." is the one tuning variable: sgp_amd/tune.py and libsgp_amd.so parse it alike."""
+    from sgp_amd import hip, tune
+    lib = hip.load()
+    monkeypatch.delenv("SGP_TUNE", raising=False)
+    assert tune.get("hop", "split") == "split" and tune.get("mix_thr", 4, int) == 4
+    assert lib.sgp_tune_value(b"spmm_chunk", 32) == 32
+    monkeypatch.setenv("SGP_TUNE", "hop=exact, spmm_chunk=16,mix_min_share=0.4,abl=3072")
+    assert tune.get("hop", "split") == "exact" and tune.get("spmm_chunk", 32, int) == 16
+    assert tune.get("mix_min_share", 0.25, float) == 0.4 and tune.get("absent", 7, int) == 7
+    assert lib.sgp_tune_value(b"spmm_chunk", 32) == 16 and lib.sgp_tune_value(b"abl", 0) == 3072
+    assert lib.sgp_tune_value(b"chunk", 5) == 5                       # a suffix of a key is not the key
+    with pytest.raises(ValueError):
+        tune.get("hop", 1, int)

@@ -11,16 +11,21 @@
 // blocks of A at 16x the fp32 rate make 256-row tiles affordable: 3.1 staged rows per result row.
 //
 // Structure (plan: sgp_amd/splitplan.py):
-//   * a workgroup of 8 waves owns a tile of up to 8 x 32 consecutive rows for a chunk of time steps; wave w
-//     owns up to 32 rows (two 16-row halves) and NCH chunks of 32 columns -- its A fragments (hi / lo piece,
-//     both halves, 16 VGPRs per chunk) are loaded once and stay in registers for the whole chunk;
-//   * a unit = (time step, 16-feature slice).  The tile's distinct source rows (<= SMAX) are loaded as 64-byte
-//     pieces (global_load_dwordx4, 4 lanes per row), scaled, split and written to LDS as two planes of fp16
-//     rows (32 B per row and plane) while the MFMAs of the previous unit run; two LDS buffers, one barrier per unit;
-//   * B operands come straight out of the row-major planes with ds_read_b64_tr_b16 (per-lane ROW addresses: the
-//     4 rows a 16-lane group reads may lie anywhere), 4 reads + 6 MFMAs per chunk;
-//   * results leave as 64-byte row pieces (16 lanes x 4 B) one unit later, in front of the next loads
-//     (stores and loads share vmcnt; this order lets one vmcnt(0) in front of the conversion cover both).
+//   * a workgroup of 8 waves owns a tile of up to 8 x 32 rows for a chunk of time steps; wave w owns up to 32 rows
+//     (two 16-row halves) and NCH chunks of 32 columns -- its A fragments (hi / lo piece, both halves, 16 VGPRs per
+//     chunk) are loaded once and stay in registers for the whole chunk;
+//   * a unit = (time step, 16-feature slice).  The tile's distinct source rows (<= SMAX) arrive as 64-byte pieces by
+//     LDS-DMA (global_load_lds_dwordx4, 4 lanes per row, optional second "halo" source) in one of THREE LDS buffers,
+//     two units ahead of the multiply; the wave that requested a piece scales and splits it IN PLACE (v_fma_mixlo /
+//     mixhi_f16) into the operand layout: 8 staged rows = 512 B, hi pieces of row r at 32 r, lo pieces at 256 + 32 r;
+//   * B operands come straight out of those fp16 rows with ds_read_b64_tr_b16 (per-lane ROW addresses: the 4 rows a
+//     16-lane group reads may lie anywhere), 4 reads + 6 MFMAs per chunk, the reads issued from asm two chunks ahead
+//     with counted lgkmcnt waits;
+//   * results: 4 x 4 transpose inside every quad of lanes (DPP) -> 16-byte row pieces; an even slice waits for its odd
+//     neighbour so that whole 128-byte lines leave together; stores are issued behind the conversion, the next unit's
+//     staging requests behind them (stores and loads share vmcnt: a wait for "all but the newest nld" then covers the
+//     pieces it is meant for whatever the stores do);
+//   * one barrier per unit.
 // Limits checked by the planner: a wave's rows touch <= 32 NCH distinct columns, a tile <= SMAX; feat % 16 == 0;
 // |x| * x_scale and |a| * w_scale must stay below 65504 (the host picks the scales from bounds).
 #include "common.h"

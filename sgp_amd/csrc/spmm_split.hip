@@ -387,9 +387,20 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     a.Y = Y; a.yrs = y_row_stride; a.ybs = y_batch_stride;
     a.batch = batch; a.nslice = feat / 16;
     if (t_chunk <= 0) {
-        // enough workgroups for ~8 rounds of the chip, chunks of at least 8 steps (the plan load is ~4 steps' worth)
-        t_chunk = 64;
-        while (t_chunk > 8 && (long long)n_tiles * ((batch + t_chunk - 1) / t_chunk) < 2048) t_chunk >>= 1;
+        // time steps per workgroup: long chunks amortise the plan load (A fragments: ~1.6 units' worth of staging per
+        // workgroup), short ones fill the last round of the chip.  Cost model: rounds taken / rounds of work x
+        // (1 + 1.6 / steps); ties go to the longer chunk.
+        int cus = 256, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+            cus = 256;
+        double best = 1e30;
+        for (int tc = 64; tc >= 8; tc >>= 1) {
+            if (tc > batch && tc > 8) continue;
+            const double w = (double)n_tiles * ((batch + tc - 1) / tc) / cus;
+            const double cost = (w <= 1.0 ? 1.0 / w : (double)(long long)(w + 0.999999) / w) * (1.0 + 1.6 / tc);
+            if (cost < best - 1e-9) { best = cost; t_chunk = tc; }
+        }
+        if (t_chunk <= 0) t_chunk = 8;
     }
     a.t_chunk = t_chunk;
     a.x_scale = x_scale; a.inv_scale = 1.f / (x_scale * w_scale);

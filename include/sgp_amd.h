@@ -221,12 +221,13 @@ int32_t sgp_spmm_split_waves(void);
  *                                 to a multiple of 64 * sgp_spmm_colblock_round_pad()
  *   segptr[n_wg * n_blocks + 1]   first ROUND (64 entries) of segment (wg, block)
  *   wg_row0[n_wg + 1]             first row of every workgroup
- * feat must be a multiple of 64 (one launch dimension per 64 features), n_cols < 2^23; no halo source
- * (a node partition of such a graph uses sgp_spmm_csr_f32).  The sums of a row meet through LDS float
+ * feat must be a multiple of 64 (one launch dimension per 64 features), n_cols < 2^22.  X_halo / n_own as in
+ * sgp_spmm_tiled_f32: columns >= n_own address the halo rows a node partition received (round 4).  The sums of a row meet through LDS float
  * atomics: their order, hence the last bits of a result, may differ between runs. */
 int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int32_t* wg_row0,
                           int32_t n_wg, int32_t n_blocks,
                           const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                          const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                           float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                           int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                           sgp_stream_t stream);

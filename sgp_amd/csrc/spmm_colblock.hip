@@ -46,12 +46,15 @@ struct CbArgs {
     const int* segptr;                        // [n_wg * nb + 1], in rounds of 64 entries
     const int* wg_row0;                       // [n_wg + 1]
     const float* x; long long xrs, xbs;
+    const float* xh; long long xhrs, xhbs;    // halo source: columns >= n_own (local block of a node partition)
+    int n_own;
     float* y; long long yrs, ybs;
     int nb, batch;
     unsigned* pace;                           // arrival counter of the per-step rendezvous, or null
     unsigned n_arrive;                        // workgroups of the launch
 };
 
+template <bool HALO>
 __global__ __launch_bounds__(kWaves * 64) void spmm_colblock(CbArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int wg = blockIdx.x;
@@ -74,10 +77,18 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_colblock(CbArgs a) {
     const int s_end = __builtin_amdgcn_readfirstlane(a.segptr[(long long)wg * a.nb + a.nb]);
     const int slot = wave * 4 + g;                        // this lane group's list inside a round
     const long long xrs_b = a.xrs * 4;
+    const long long xhrs_b = a.xhrs * 4;
     const uint2* pl = a.plan + slot;
     bool paced = a.pace != nullptr;
     for (int t = 0; t < a.batch; ++t) {
         const char* xt = reinterpret_cast<const char*>(a.x + (long long)t * a.xbs + f_base) + li * 16;
+        const char* xht = HALO ? reinterpret_cast<const char*>(a.xh + (long long)t * a.xhbs + f_base) + li * 16 : nullptr;
+        // source row of a plan entry: own rows from x, columns >= n_own from the halo rows the partition received
+        auto src = [&](unsigned e) -> const f32x4* {
+            const int c = (int)(e & 0x3fffffu);
+            if (HALO && c >= a.n_own) return reinterpret_cast<const f32x4*>(xht + (long long)(c - a.n_own) * xhrs_b);
+            return reinterpret_cast<const f32x4*>(xt + (long long)c * xrs_b);
+        };
         uint2 e0[kU], e1[kU], e2[kU];
         f32x4 x0[kU], x1[kU];
 #pragma unroll
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_colblock(CbArgs a) {
 #pragma unroll
         for (int u = 0; u < kU; ++u) e1[u] = pl[(long long)(s_begin + kU + u) * 64];
 #pragma unroll
-        for (int u = 0; u < kU; ++u) x0[u] = *reinterpret_cast<const f32x4*>(xt + (long long)(e0[u].x & 0x3fffffu) * xrs_b);
+        for (int u = 0; u < kU; ++u) x0[u] = *src(e0[u].x);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int r = s_begin; r < s_end; r += kU) {
 #pragma unroll
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(kWaves * 64) void spmm_colblock(CbArgs a) {
                 e2[u] = make_uint2(v.x, v.y);
             }
 #pragma unroll
-            for (int u = 0; u < kU; ++u) x1[u] = *reinterpret_cast<const f32x4*>(xt + (long long)(e1[u].x & 0x3fffffu) * xrs_b);
+            for (int u = 0; u < kU; ++u) x1[u] = *src(e1[u].x);
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 acc += __uint_as_float(e0[u].y) * x0[u];
@@ -138,6 +149,7 @@ int32_t sgp_spmm_colblock_round_pad(void) { return kU; }
 int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int32_t* wg_row0,
                           int32_t n_wg, int32_t n_blocks,
                           const float* X, int64_t xrs, int64_t xbs,
+                          const float* X_halo, int64_t xhrs, int64_t xhbs, int32_t n_own,
                           float* Y, int64_t yrs, int64_t ybs,
                           int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                           sgp_stream_t stream) {
@@ -151,9 +163,13 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
     SGP_REQUIRE(xrs % 4 == 0 && xbs % 4 == 0 && yrs % 4 == 0 && ybs % 4 == 0 && sgp::aligned16(X) && sgp::aligned16(Y),
                 "sgp_spmm_colblock_f32: strides/pointers must be 16-byte aligned");
     SGP_REQUIRE((long long)n_cols * xrs < (1ll << 40) && feat / 64 <= 65535, "sgp_spmm_colblock_f32: operand too large");
+    SGP_REQUIRE(!X_halo || (n_own >= 0 && n_own <= n_cols && xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(X_halo) &&
+                            (long long)(n_cols - n_own) * xhrs < (1ll << 40)),
+                "sgp_spmm_colblock_f32: halo rows must be 16-byte aligned, n_own within the columns");
     CbArgs a;
     a.plan = reinterpret_cast<const uint2*>(plan); a.segptr = segptr; a.wg_row0 = wg_row0;
     a.x = X; a.xrs = xrs; a.xbs = xbs; a.y = Y; a.yrs = yrs; a.ybs = ybs;
+    a.xh = X_halo; a.xhrs = xhrs; a.xhbs = xhbs; a.n_own = X_halo ? n_own : 0x7fffffff;
     a.nb = n_blocks; a.batch = batch;
     hipStream_t s = (hipStream_t)stream;
     // per-step rendezvous only when all workgroups are resident at once (one per CU: 128 KB of LDS each)
@@ -166,10 +182,11 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
             a.pace = sgp::sync_slot(s);              // this launch's own counter (two launches in flight never share one)
     }
     const size_t lds_bytes = 512 * 256;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(spmm_colblock),
+    auto kern = X_halo ? spmm_colblock<true> : spmm_colblock<false>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "spmm_colblock: LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(spmm_colblock, dim3((unsigned)n_wg, (unsigned)(feat / 64)), dim3(kWaves * 64), lds_bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)n_wg, (unsigned)(feat / 64)), dim3(kWaves * 64), lds_bytes, s, a);
     return sgp::check_launch("spmm_colblock");
 }
 

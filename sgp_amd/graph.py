@@ -374,15 +374,16 @@ class ShiftOperator:
         # 3. no tile plan (no locality to stage): when a time step's source rows exceed an L2 and the rows
         # are not nearly empty, the column-blocked kernel keeps the gathers inside the L2 (random 100-column
         # rows at N = 100k: 1.3x the generic kernel); small or very sparse operators stay with CSR
-        if force == "colblock" or (force is None and plan is None and halo is None and fits32
+        if force == "colblock" or (force is None and plan is None and fits32
                                    and x.shape[2] % 64 == 0 and x.shape[0] >= 4
                                    and self.num_cols * x.shape[2] * 4 > 3 * 2 ** 20
                                    and self.nnz() >= 16 * self.num_nodes
                                    and tune.get("colblock", 1, int) != 0):
-            cplan = self.colblock_plan(x.shape[2], x.device) if halo is None else None
+            ok_halo = halo is None or (halo.stride(1) % 4 == 0 and halo.stride(0) % 4 == 0 and halo.data_ptr() % 16 == 0)
+            cplan = self.colblock_plan(x.shape[2], x.device) if ok_halo else None
             if cplan is not None:
                 self.last_kernel = "spmm_colblock"
-                hip.spmm_colblock(cplan, x, y)
+                hip.spmm_colblock(cplan, x, y, halo, self.num_nodes)
                 return y
             if force == "colblock":
                 raise NotImplementedError("no column-blocked plan for this operator / feature width / halo")

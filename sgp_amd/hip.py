@@ -115,7 +115,8 @@ SIGNATURES = {
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
     "sgp_spmm_split_waves": (c_i32, []),
-    "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+    "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64,
+                                             c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
                                              c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_spmm_colblock_rows_cap": (c_i32, []),
     "sgp_spmm_colblock_round_pad": (c_i32, []),
@@ -346,15 +347,20 @@ def spmm_split(plan, x, y, x_bound, t_chunk=0, halo=None, n_own=None):
 
 
 @_on_device
-def spmm_colblock(plan, x, y):
+def spmm_colblock(plan, x, y, halo=None, n_own=None):
     """Column-blocked hop for graphs without locality (plan: sgp_amd.colblock.ColBlockPlan on the device
     of ``x``)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
     yp, yrs, ybs = _view3(y, "y")
+    if halo is not None:
+        hp, hrs, hbs = _view3(halo, "halo")
+        n_own = x.shape[1] if n_own is None else n_own
+    else:
+        hp, hrs, hbs, n_own = None, 0, 0, 0
     _check(lib.sgp_spmm_colblock_f32(
         plan.entries.data_ptr(), plan.segptr.data_ptr(), plan.wg_row0.data_ptr(), plan.n_wg, plan.n_blocks,
-        xp, xrs, xbs, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], _stream(x)),
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], _stream(x)),
         "sgp_spmm_colblock_f32")
 
 

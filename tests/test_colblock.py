@@ -164,3 +164,32 @@ def test_colblock_nan_in_one_source_row_stays_in_the_rows_that_reference_it():
     y1 = torch.empty_like(y0)
     hip.spmm_colblock(many, x0.cuda(), y1)
     assert torch.allclose(y1, y0, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_colblock_partitioned_blocks_with_halo(world):
+    """Local blocks of a node partition of a graph WITHOUT locality (round 4: halo source): the rows arrive as a
+    second source in the [rows, T, D] layout of the exchange; chosen automatically once a time step's source rows
+    exceed an L2."""
+    from sgp_amd import partition
+    torch.manual_seed(world)
+    n, t, d = 24000, 5, 64
+    ei, ew = synthetic.random_graph(n, 100, seed=3)               # 100 columns per row: no 16-row tile fits the LDS
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    x = torch.randn(t, n, d)
+    whole = torch.empty(t, n, d, device="cuda")
+    op.propagate(x.cuda(), whole, force="csr")
+    bounds = partition.partition_bounds(n, world)
+    for r in range(world):
+        blk = partition.split_operator(op, bounds, r)
+        assert blk.n_halo >= (n - blk.n_own) * 9 // 10               # no locality: the halo is (nearly) everything else
+        xo = x[:, blk.lo:blk.hi].cuda().contiguous()
+        recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()
+        y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
+        blk.op.propagate(xo, y, halo=recv.permute(1, 0, 2))
+        assert blk.op.last_kernel == "spmm_colblock"
+        assert torch.allclose(y, whole[:, blk.lo:blk.hi], rtol=1e-5, atol=1e-5)
+        y2 = torch.empty_like(y)
+        blk.op.propagate(xo, y2, force="csr", halo=recv.permute(1, 0, 2))
+        assert torch.allclose(y, y2, rtol=1e-6, atol=1e-6)

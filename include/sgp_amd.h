@@ -192,12 +192,13 @@ int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride
  * by v_mfma_f32_16x16x32_f16: results agree with an fp32 evaluation to ~1e-7 of the input scale (measured
  * against fp64: closer than an fp32 fma chain), at 16x the fp32 matrix rate, which pays for dense 16 x 32
  * blocks of A and 256-row tiles (3.1 staged source rows per result row instead of 5.8).  Arrays:
- *   hdr[n_tiles][32]                         [8:16] rows of each of the 8 waves, [16] staged rows U
- *   rowid[n_tiles][8][32]                    result row of every slot (16 half + m) of every wave, -1 = empty
+ *   hdr[n_tiles][64]                         [W : 2 W] rows of each of the W waves, [2 W] staged rows U
+ *   rowid[n_tiles][W][rows]                  result row of every slot (16 half + m) of every wave, -1 = empty
  *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
- *   afr[n_tiles][8][chunks][4][64][8] fp16   A fragments in lane order (2 * half + piece)
- *   adr[n_tiles][8][chunks][2][64]           per-lane plane byte address of the transpose reads
- * with chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0.  X / X_halo /
+ *   afr[n_tiles][W][chunks][rows / 8][64][8] fp16   A fragments in lane order (2 * half + piece)
+ *   adr[n_tiles][W][chunks][2][64]           per-lane byte address of the transpose reads
+ * with W = sgp_spmm_split_waves(), rows = sgp_spmm_split_rows_per_wave() (8 x 32 or 16 x 16: a build parameter),
+ * chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0.  X / X_halo /
  * n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows a node partition received).  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
  * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */
 int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
@@ -210,6 +211,7 @@ int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* 
 int32_t sgp_spmm_split_chunks(void);
 int32_t sgp_spmm_split_max_union(void);
 int32_t sgp_spmm_split_waves(void);
+int32_t sgp_spmm_split_rows_per_wave(void);
 
 /* Column-blocked hop for graphs without locality (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/colblock.py).  The columns are cut into n_blocks blocks of consecutive columns whose source

@@ -55,6 +55,35 @@ __global__ void pack_weights(const float* __restrict__ w_ih, const float* __rest
     }
 }
 
+// one thread per (jt, kb, lane): 8 weights -> 3 x 16 bytes
+__global__ void pack_weights_bf3(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                 const float* __restrict__ b, char* __restrict__ out, int F, int R, int JT, int NKX) {
+    const int KBH = bf3_kbh(JT), KB = KBH + bf3_kbx(NKX);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < JT * 16) reinterpret_cast<float*>(out)[i] = i < R ? b[i] : 0.f;
+    if (i >= JT * KB * 64) return;
+    const int l = i & 63, kb = (i >> 6) % KB, jt = (i >> 6) / KB;
+    const int j = 16 * jt + (l & 15), g = l >> 4;
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (kb < KBH) {
+            const int tt = 2 * kb + (s >> 2), k = 16 * tt + 4 * g + (s & 3);
+            w[s] = (j < R && tt < JT && k < R) ? w_hh[(long long)j * R + k] : 0.f;
+        } else {
+            const int ks = 8 * (kb - KBH) + s, k = bf3_feature(NKX, g, ks);
+            w[s] = (j < R && ks < NKX && k < F) ? w_ih[(long long)j * F + k] : 0.f;
+        }
+    }
+    u32x4 p1, p2, p3;
+    bf3_split8(w, p1, p2, p3);
+    u32x4* o = reinterpret_cast<u32x4*>(out + (long long)JT * 64) + ((long long)(jt * KB + kb) * 3) * 64 + l;
+    o[0] = p1; o[64] = p2; o[128] = p3;
+}
+
+
+long long bf3_offset(int jt, int nkx) { return (packed_floats(jt, nkx) * 4 + 255) / 256 * 256; }
+
 int pick_nkx(int F) {
     const int need = (F + 3) / 4;
     const int opts[] = {1, 2, 4, 8, 16, 32, 64};
@@ -76,7 +105,8 @@ extern "C" {
 int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     const int jt = pick_jt(R), nkx = pick_nkx(F);
     if (!jt || !nkx) return -1;
-    return packed_floats(jt, nkx) * 4;
+    // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
+    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0);
 }
 
 int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
@@ -105,6 +135,17 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     ResArgs a;
     a.x = x; a.xrs = xrs; a.xss = xss;
     a.wp = (const float*)workspace;
+    a.wp_bf3 = nullptr;
+    // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
+    static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
+    if (use_bf3 && bf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) {
+        char* wb = (char*)workspace + bf3_offset(jt, nkx);
+        const int threads = jt * (bf3_kbh(jt) + bf3_kbx(nkx)) * 64;
+        hipLaunchKernelGGL(pack_weights_bf3, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wb, F, R, jt, nkx);
+        rc = sgp::check_launch("pack_weights_bf3");
+        if (rc) return rc;
+        a.wp_bf3 = wb;
+    }
     a.out = out; a.ors = ors; a.oss = oss;
     a.h_state = h_state;
     a.alpha = (float)alpha;                      // scalar operands are rounded to fp32 like

@@ -1,0 +1,284 @@
+// Leaky echo-state layer on the 16-bit matrix cores with fp32-grade products (included by reservoir_impl.h
+// inside namespace sgp_res; reference: lib/nn/reservoir/reservoir.py:77-81 stepped by :170-183).
+//
+// The exact-fp32 kernel (reservoir_layer) is bound by the matrix pipe: v_mfma_f32_16x16x4_f32 delivers 1/16 of the
+// 16-bit rate, and at R = F = 64 its 128 MFMAs per tile and step take 4096 cycles of a SIMD -- 10.7 ms per 1024 steps
+// of the target line against 8.7 ms for the layer's HBM traffic at the achievable rate.  Here every fp32 operand is cut
+// into THREE bf16 pieces, v = b1 + b2 + b3 with b1 = rne(v), b2 = rne(v - b1), b3 = rne(v - b1 - b2): 24 significant
+// bits, no scale and no bound on |v| needed (bf16 has the exponent range of fp32), and the product is summed from the
+// six piece products of order <= 2^-16,
+//     w v = w1 v1 + w1 v2 + w2 v1 + w1 v3 + w2 v2 + w3 v1        (+ O(2^-25) |w v| left out),
+// on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: 6 x 1/8 of the MFMA instructions, each half as long -- 3/8 of
+// the matrix time -- and an error per product below that of ONE fp32 rounding (measured against fp64 in
+// tests/test_gpu_reservoir_bf3.py).  Any activation, any input: the kernel needs no bound on the state.
+//
+// Layout: as in reservoir_layer the contraction is computed transposed, D[j, n] += W[j, k] hT[k, n], so that the
+// accumulator (lane = node n + 16 q, register r <-> unit 16 jt + 4 q + r) feeds the next step's B operand without
+// leaving its lane: k-block p of the recurrent part takes the lane's 8 values of state tiles 2p and 2p + 1 as its
+// 8 k-slots (slot i <-> unit 16 (2p + i / 4) + 4 q + i % 4), and the same permutation is baked into the packed
+// W_hh fragments.  Of an input row a lane holds NKX features (register ks <-> feature bf3_feature(NKX, q, ks): 16-byte
+// pieces that make 64 consecutive bytes per node and load instruction), k-block p of the input part takes
+// ks = 8p .. 8p + 7.
+//
+// Packed weights (device workspace, copied to LDS by every workgroup):
+//   bias  [JT][16] fp32
+//   frag  [JT][KBH + KBX][3 pieces][64 lanes][8 bf16]     (16 bytes per lane: one ds_read_b128 per MFMA operand)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int bf3_kbh(int JT) { return (JT + 1) / 2; }
+__host__ __device__ constexpr int bf3_kbx(int NKX) { return (NKX + 7) / 8; }
+__host__ __device__ constexpr long long bf3_packed_bytes(int JT, int NKX) {
+    return (long long)JT * 64 + (long long)JT * (bf3_kbh(JT) + bf3_kbx(NKX)) * 3 * 1024;
+}
+
+// narrow reservoirs and inputs: the state (16 JT), the input rows (4 NKX values per node) and the pieces of one
+// k-block fit the 128 registers of four waves per SIMD
+__host__ __device__ constexpr bool bf3_supported(int JT, int NKX) {
+    return (JT == 2 || JT == 4) && (NKX == 4 || NKX == 8 || NKX == 16) && bf3_packed_bytes(JT, NKX) <= 64 * 1024;
+}
+
+
+// input feature held by lane group q in its register ks
+__host__ __device__ constexpr int bf3_feature(int NKX, int q, int ks) {
+    return NKX % 4 == 0 ? 16 * (ks >> 2) + 4 * q + (ks & 3) : q * NKX + ks;
+}
+
+__device__ __forceinline__ unsigned bf3_pk(float a, float b) {        // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// two values -> one dword of each piece (low half = a, high half = b)
+__device__ __forceinline__ void bf3_split2(float a, float b, unsigned& p1, unsigned& p2, unsigned& p3) {
+    p1 = bf3_pk(a, b);
+    const float a1 = a - __builtin_bit_cast(float, p1 << 16), b1 = b - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = bf3_pk(a1, b1);
+    const float a2 = a1 - __builtin_bit_cast(float, p2 << 16), b2 = b1 - __builtin_bit_cast(float, p2 & 0xffff0000u);
+    p3 = bf3_pk(a2, b2);
+}
+__device__ __forceinline__ void bf3_split8(const float (&v)[8], u32x4& p1, u32x4& p2, u32x4& p3) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        unsigned a, b, c;
+        bf3_split2(v[2 * d], v[2 * d + 1], a, b, c);
+        p1[d] = a; p2[d] = b; p3[d] = c;
+    }
+}
+// acc += (w1 + w2 + w3) (v1 + v2 + v3), the six products of order <= 2^-16, smallest first
+__device__ __forceinline__ f32x4 bf3_mac(const u32x4& w1, const u32x4& w2, const u32x4& w3,
+                                         const u32x4& v1, const u32x4& v2, const u32x4& v3, f32x4 acc) {
+    const bf16x8 W1 = __builtin_bit_cast(bf16x8, w1), W2 = __builtin_bit_cast(bf16x8, w2), W3 = __builtin_bit_cast(bf16x8, w3);
+    const bf16x8 V1 = __builtin_bit_cast(bf16x8, v1), V2 = __builtin_bit_cast(bf16x8, v2), V3 = __builtin_bit_cast(bf16x8, v3);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W3, V1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W2, V2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1, V3, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W2, V1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1, V2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W1, V1, acc, 0, 0, 0);
+    return acc;
+}
+
+// byte offset of the fragment of output tile jt, k-block kb, piece pc (0 = leading piece)
+__host__ __device__ constexpr int bf3_frag_off(int KB, int jt, int kb, int pc) { return ((jt * KB + kb) * 3 + pc) * 1024; }
+// units of the MFMA phase: (k-block, pair of output tiles); the input blocks come first
+__host__ __device__ constexpr int bf3_unit_kb(int JT, int NKX, int u) {
+    const int b = u / (JT / 2);
+    return b < bf3_kbx(NKX) ? bf3_kbh(JT) + b : b - bf3_kbx(NKX);
+}
+
+// experiment switches (build with -DSGP_BF3_ABL=bits): 1 no MFMAs, 2 no piece conversion, 4 no activation,
+// 8 no stores, 16 input rows loaded once
+#ifndef SGP_BF3_ABL
+#define SGP_BF3_ABL 0
+#endif
+constexpr bool bf3_abl(int bit) { return (SGP_BF3_ABL & bit) != 0; }
+
+template <int I> struct Bf3C { static constexpr int value = I; };
+template <int B, int E, class F>
+__device__ __forceinline__ void bf3_for(F&& f) {
+    if constexpr (B < E) { f(Bf3C<B>{}); bf3_for<B + 1, E>(f); }
+}
+// weight fragments are read by hand (the compiler would put every ds_read in front of an s_waitcnt lgkmcnt(0))
+template <int OFF> __device__ __forceinline__ void bf3_rd(u32x4& d, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
+}
+template <int N> __device__ __forceinline__ void bf3_wait(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
+}
+__device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
+    if constexpr (bf3_abl(1)) { acc[0] += __builtin_bit_cast(float, w[0] ^ v[0]); return acc; }
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
+}
+
+// Exact widths only (R = 16 JT, F = 4 NKX, 16-byte aligned rows): every load and store of the time loop is
+// unconditional and the loop body is straight-line code, so that the compiler counts its memory operations exactly
+// (s_waitcnt vmcnt(4) for the input rows with the four stores behind them still in flight).  With a branch around any
+// of them -- an exec-masked store, a wave-uniform `tile exists` test -- it falls back to vmcnt(0) at the top of every
+// tile and step, and the step waits for its own stores to reach memory (measured: 5360 cycles per tile and step).
+// N is a multiple of 16 here: the nodes of a ragged last tile go to the exact-fp32 kernel (launch_layer).
+template <int JT, int NKX, int NT>
+__global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int KBH = bf3_kbh(JT), KBX = bf3_kbx(NKX), KB = KBH + KBX, NP = JT / 2, NU = KB * NP;
+    {
+        const int total4 = (int)(bf3_packed_bytes(JT, NKX) / 16);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x)
+            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wp_bf3)[i];
+        __syncthreads();
+    }
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    int tile0, tile1;                                        // the deal of reservoir_layer
+    if (a.tiles_per_wave > 0) {
+        const int per = a.tiles_per_wave;
+        const int wl = threadIdx.x >> 6, c = wl & 3, k = wl >> 2;
+        const int base = per >> 2, extra = per & 3;
+        tile0 = (blockIdx.x * 4 + c) * per + k * base + min(k, extra);
+        tile1 = min(tile0 + base + (k < extra ? 1 : 0), a.n_tiles);
+    } else {
+        const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        const int n_waves = gridDim.x * (blockDim.x >> 6);
+        tile0 = (int)((long long)wave * a.n_tiles / n_waves);
+        tile1 = (int)((long long)(wave + 1) * a.n_tiles / n_waves);
+    }
+    if (tile0 >= tile1) return;
+    const int my_nt = tile1 - tile0;
+
+    // byte offsets of this lane's 16-byte piece of its node's input row / state row (32 bits: checked on the host)
+    unsigned xo[NT], oo[NT];
+    f32x4 h[NT][JT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int node = (tile0 + (i < my_nt ? i : 0)) * 16 + n_in;
+        xo[i] = (unsigned)((node * a.xrs + 4 * q) * 4);
+        oo[i] = (unsigned)((node * a.ors + 4 * q) * 4);
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) {
+            h[i][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.h_state && i < my_nt) h[i][jt] = *reinterpret_cast<const f32x4*>(a.h_state + (long long)node * a.R + 16 * jt + 4 * q);
+        }
+    }
+    // the input rows of ONE tile and step (register 4 k4 + s <-> feature 16 k4 + 4 q + s: the four lanes of a node read
+    // 64 consecutive bytes per instruction): requested right after the rows before them were consumed (the input
+    // part runs first), so they are in flight under the recurrent part, the activation and the stores of that tile
+    f32x4 xr[NKX / 4];
+    auto load_x = [&](int t, int i) {
+        const char* xp = reinterpret_cast<const char*>(a.x + (long long)t * a.xss);
+#pragma unroll
+        for (int k4 = 0; k4 < NKX / 4; ++k4) xr[k4] = *reinterpret_cast<const f32x4*>(xp + xo[i] + 64 * k4);
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the initial state has landed
+    load_x(0, 0);
+    const unsigned fa = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + JT * 16) + lane * 16;
+
+
+    auto run = [&](auto mtc) {
+        constexpr int MT = decltype(mtc)::value;
+        for (int t = 0; t < a.T; ++t) {
+            int wo = 0;                                      // keeps the bias reads inside the loop (see reservoir_layer)
+            asm volatile("" : "+v"(wo));
+            const float* bias_t = lds + wo;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                f32x4 acc[JT];
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+                // Ring of six fragment registers: [0,1] = third pieces of the unit's two output tiles, [2,3] = second,
+                // [4,5] = leading.  A unit multiplies 2 x (1 + 2 + 3) products, the two tiles' chains alternating (no
+                // MFMA waits for the one before it); the next unit's pieces are requested as soon as their registers
+                // are free: third pieces 10 MFMAs ahead of their use, second 8, leading 6.
+                u32x4 ring[6];
+                bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 2)>(ring[1], fa);
+                bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 1)>(ring[3], fa);
+                u32x4 v1, v2, v3;
+                bf3_for<0, NU>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value, kb = bf3_unit_kb(JT, NKX, u), j0 = 2 * (u % NP), j1 = j0 + 1;
+                    constexpr bool last = u + 1 == NU;
+                    constexpr int un = last ? 0 : u + 1, kbn = bf3_unit_kb(JT, NKX, un), n0 = 2 * (un % NP), n1 = n0 + 1;
+                    if constexpr (u % NP == 0) {             // the pieces of a new k-block
+                        float v[8];
+                        if constexpr (kb >= KBH) {
+                            constexpr int p = kb - KBH;
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) v[s] = h[i][2 * kb + (s >> 2)][s & 3];
+                        }
+                        if constexpr (bf3_abl(2)) {
+#pragma unroll
+                            for (int d = 0; d < 4; ++d) { v1[d] = __builtin_bit_cast(unsigned, v[2 * d]); v2[d] = __builtin_bit_cast(unsigned, v[2 * d + 1]); v3[d] = v1[d] ^ v2[d]; }
+                        } else {
+                            bf3_split8(v, v1, v2, v3);
+                        }
+                        if constexpr (kb == KBH + KBX - 1 && !bf3_abl(16)) {
+                            // the input rows are consumed: request those of this wave's next tile and step (the last
+                            // step re-reads its own rows instead of branching)
+                            if (i + 1 < MT) load_x(t, i + 1 < MT ? i + 1 : 0);
+                            else load_x(t + 1 < a.T ? t + 1 : t, 0);
+                        }
+                    }
+                    bf3_rd<bf3_frag_off(KB, j0, kb, 0)>(ring[4], fa); bf3_rd<bf3_frag_off(KB, j1, kb, 0)>(ring[5], fa);
+                    bf3_wait<4>(ring[0], ring[1]);
+                    acc[j0] = bf3_mfma(ring[0], v1, acc[j0]); acc[j1] = bf3_mfma(ring[1], v1, acc[j1]);
+                    if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 2)>(ring[1], fa); }
+                    bf3_wait<last ? 2 : 4>(ring[2], ring[3]);
+                    acc[j0] = bf3_mfma(ring[2], v2, acc[j0]); acc[j1] = bf3_mfma(ring[3], v2, acc[j1]);
+                    acc[j0] = bf3_mfma(ring[2], v1, acc[j0]); acc[j1] = bf3_mfma(ring[3], v1, acc[j1]);
+                    if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 1)>(ring[3], fa); }
+                    bf3_wait<last ? 0 : 4>(ring[4], ring[5]);
+                    acc[j0] = bf3_mfma(ring[4], v3, acc[j0]); acc[j1] = bf3_mfma(ring[5], v3, acc[j1]);
+                    acc[j0] = bf3_mfma(ring[4], v2, acc[j0]); acc[j1] = bf3_mfma(ring[5], v2, acc[j1]);
+                    acc[j0] = bf3_mfma(ring[4], v1, acc[j0]); acc[j1] = bf3_mfma(ring[5], v1, acc[j1]);
+                });
+                // activation
+                if (bf3_abl(4)) {
+                } else if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
+                } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+                } else if (a.act == SGP_ACT_SELF_NORM) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ss = fmaf(acc[jt][r], acc[jt][r], ss);
+                    ss += __shfl_xor(ss, 16);
+                    ss += __shfl_xor(ss, 32);
+                    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize(eps=1e-12)
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
+                }
+                // leak + store
+                char* op = reinterpret_cast<char*>(a.out + (long long)t * a.oss);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
+                                                            : leak(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
+                    if (!bf3_abl(8) || t == 0) *reinterpret_cast<f32x4*>(op + oo[i] + 64 * jt) = h[i][jt];
+                }
+            }
+        }
+    };
+    if (NT > 1 && my_nt > 1) run(Bf3C<NT>{}); else run(Bf3C<1>{});
+    if (a.h_state) {
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+                if (i < my_nt) *reinterpret_cast<f32x4*>(a.h_state + (long long)((tile0 + i) * 16 + n_in) * a.R + 16 * jt + 4 * q) = h[i][jt];
+    }
+}

@@ -58,6 +58,7 @@ __device__ __forceinline__ float leak_tanh_r(float h, float r, float alpha, floa
 struct ResArgs {
     const float* x; long long xrs, xss;
     const float* wp;                 // packed weights (global workspace)
+    const void* wp_bf3;              // the same weights as bf16 piece fragments (reservoir_bf3.h), or null
     float* out; long long ors, oss;
     float* h_state;
     float alpha, one_minus_alpha;
@@ -265,6 +266,8 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
 
 
 constexpr int kLdsLimit = 160 * 1024;
+
+#include "reservoir_bf3.h"
 
 #ifdef SGP_RES_STREAM_TU
 // ---- wide reservoirs (R = 256): weights do not fit the LDS, stream them THROUGH it ----------
@@ -980,6 +983,35 @@ int launch_layer(ResArgs a, hipStream_t s) {
     const bool xv = (NKX % 4 == 0) && (a.F % 4 == 0) && (a.xrs % 4 == 0) && (a.xss % 4 == 0) && sgp::aligned16(a.x);
     const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
     void (*kern)(ResArgs);
+    if constexpr (bf3_supported(JT, NKX)) {
+        // three-piece bf16 products (reservoir_bf3.h): 3/8 of the matrix time of the exact-fp32 kernel
+        // exact widths, 16-byte rows, row offsets in 32 bits; the nodes of a ragged last tile (N % 16) go to the
+        // exact-fp32 kernel in a second launch
+        const long long n16 = a.N / 16 * 16;
+        if (a.wp_bf3 && ov && xv && a.R == 16 * JT && a.F == 4 * NKX && n16 > 0 &&
+            n16 * a.xrs * 4 < (1ll << 32) && n16 * a.ors * 4 < (1ll << 32)) {
+            kern = reservoir_layer_bf3<JT, NKX, NT>;
+            const int bytes = (int)bf3_packed_bytes(JT, NKX);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+            ResArgs m = a;
+            m.N = (int)n16;
+            m.n_tiles = (int)(n16 / 16);
+            if (a.tiles_per_wave <= 0 && m.n_tiles <= 1024) grid = m.n_tiles;
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)bytes, s, m);
+            int rc = sgp::check_launch("reservoir_layer_bf3");
+            if (rc || n16 == a.N) return rc;
+            ResArgs r = a;                                   // the last, ragged tile
+            r.wp_bf3 = nullptr;
+            r.tiles_per_wave = 0;
+            r.x = a.x + n16 * a.xrs;
+            r.out = a.out + n16 * a.ors;
+            if (a.h_state) r.h_state = a.h_state + n16 * a.R;
+            r.N = a.N - (int)n16;
+            return launch_layer<JT, NKX, 1>(r, s);
+        }
+    }
     constexpr bool kLds = packed_floats(JT, NKX) * 4 <= kLdsLimit;
     if (xv && ov) kern = reservoir_layer<JT, NKX, NT, kLds, true, true>;
     else if (ov) kern = reservoir_layer<JT, NKX, NT, kLds, false, true>;

@@ -39,9 +39,14 @@ typedef short s4v __attribute__((ext_vector_type(4)));
 typedef short s8v __attribute__((ext_vector_type(8)));
 using sgp::f32x4;
 
-constexpr int NW = 8;                        // waves per workgroup
+#ifndef SGP_SPLIT_NW
+#define SGP_SPLIT_NW 8
+#endif
+constexpr int NW = SGP_SPLIT_NW;             // waves per workgroup: 8 (two 16-row halves per wave) or 16 (one)
+constexpr int NH = NW == 8 ? 2 : 1;          // 16-row halves per wave
+static_assert(NW == 8 || NW == 16, "a tile is 256 rows: 8 waves x 32 or 16 waves x 16");
 #ifndef SGP_SPLIT_NCH
-#define SGP_SPLIT_NCH 9
+#define SGP_SPLIT_NCH (SGP_SPLIT_NW == 8 ? 9 : 8)
 #endif
 constexpr int NCH = SGP_SPLIT_NCH;           // resident 32-column chunks per wave (experiment builds: -DSGP_SPLIT_NCH=..)
 #ifndef SGP_SPLIT_SMAX
@@ -51,7 +56,7 @@ constexpr int SMAX = SGP_SPLIT_SMAX;         // staged rows per tile (3 x 64 x S
 constexpr int NLD = (SMAX + 16 * NW - 1) / (16 * NW);   // LDS-DMA instructions per wave and unit (16 rows each)
 constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
 constexpr int NBUF = 3;                      // landing | being converted | being multiplied
-constexpr int HDR = 32;                      // ints per tile header: [8:16] rows of every wave, [16] staged rows U
+constexpr int HDR = 64;                      // ints per tile header: [NW : 2 NW] rows of every wave, [2 NW] staged rows U
 
 // ablation / timeline switches (SGP_TUNE=split_abl=..) exist only in builds with -DSGP_ABLATION (tools/build_variant.sh):
 // the product kernel carries none of their tests
@@ -131,7 +136,7 @@ __device__ __forceinline__ void split4(const f32x4 v, const float s, uint2& hi, 
 }
 
 template <bool HALO>
-__global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
+__global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
 
     // XCD x (= blockIdx % 8) walks its own contiguous range of tiles, time chunk by time chunk, so the 32
@@ -151,15 +156,15 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
 
     // ---- resident plan: A fragments and per-lane row addresses of the transpose reads
-    h8 af[NCH][4];
+    h8 af[NCH][2 * NH];
     int ad[NCH][2];
     {
-        const h8* ap = a.afr + ((size_t)(tile * NW + wave) * NCH * 4) * 64 + lane;
+        const h8* ap = a.afr + ((size_t)(tile * NW + wave) * NCH * 2 * NH) * 64 + lane;
         const int* dp = a.adr + ((size_t)(tile * NW + wave) * NCH * 2) * 64 + lane;
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) af[c][q] = ap[(c * 4 + q) * 64];
+            for (int q = 0; q < 2 * NH; ++q) af[c][q] = ap[(c * 2 * NH + q) * 64];
             ad[c][0] = dp[(c * 2 + 0) * 64];
             ad[c][1] = dp[(c * 2 + 1) * 64];
         }
@@ -232,8 +237,8 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     };
     // after the transpose this lane stores row slots my_slot (half 0) and 16 + my_slot (half 1); -1 = empty slot
     const int my_slot = 4 * (lane >> 4) + (lane & 3);
-    const int* rid = a.rowid + (size_t)(tile * NW + wave) * 32;
-    const int row_a = rid[my_slot], row_b = rid[16 + my_slot];
+    const int* rid = a.rowid + (size_t)(tile * NW + wave) * (16 * NH);
+    const int row_a = rid[my_slot], row_b = NH == 2 ? rid[(NH - 1) * 16 + my_slot] : -1;
     const long long yoff_a = (long long)row_a * a.yrs + 4 * ((lane >> 2) & 3);
     const long long yoff_b = (long long)row_b * a.yrs + 4 * ((lane >> 2) & 3);
 
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
     // every wave multiplies first, then converts (three same-lease A/B runs: 17.7-18.1 ms per hop against 18.6-19.0 with
     // the two waves of a SIMD in opposite order -- a conversion beside the partner's MFMAs takes twice as long);
     // mode 128 selects the opposite order
-    const bool late = (wave >> 2) != 0 && ABL(128);
+    const bool late = wave >= NW / 2 && ABL(128);
     f32x4 h0 = {0, 0, 0, 0}, h1 = {0, 0, 0, 0};
     auto stamp = [&](int u, int k) {
         if (ABL(256) && blockIdx.x == 0 && lane == 0 && u >= 16 && u < 24)
@@ -308,14 +313,23 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
                 else if (c + 1 < NCH) tr_wait<4>(x);
                 else tr_wait<0>(x);
                 const h8 bh = cat8(x.h0, x.h1), bl = cat8(x.l0, x.l1);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bh, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2], bl, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][3], bh, acc1, 0, 0, 0);
+                if constexpr (NH == 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1)], bh, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1)], bl, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1) + 1], bh, acc1, 0, 0, 0);
+                } else {
+                    // one half per wave: the cross terms go to a second accumulator so that consecutive MFMAs do
+                    // not wait for each other's result (four waves per SIMD fill the rest)
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc1, 0, 0, 0);
+                }
                 if (c < NLD && dma_now && !late && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024));
             }
+            if constexpr (NH == 1) acc0 += acc1;
         } else if (dma_now && !late) {
 #pragma unroll
             for (int i = 0; i < NLD; ++i)
@@ -327,7 +341,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
         if (!ABL(4)) {
             f32x4 r0 = acc0 * a.inv_scale, r1 = acc1 * a.inv_scale;
             quad_transpose(r0);
-            quad_transpose(r1);
+            if constexpr (NH == 2) quad_transpose(r1);
             // an even slice waits for its odd neighbour: the two 64-byte halves of a 128-byte line leave together
             if (!(sl & 1) && sl + 1 < a.nslice && !ABL(32)) {
                 h0 = r0; h1 = r1;
@@ -335,10 +349,10 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
                 float* yb = a.Y + (long long)t * a.ybs + sl * 16;
                 if ((sl & 1) && !ABL(32)) {
                     if (row_a >= 0) { *(f32x4*)(yb + yoff_a - 16) = h0; *(f32x4*)(yb + yoff_a) = r0; }
-                    if (row_b >= 0) { *(f32x4*)(yb + yoff_b - 16) = h1; *(f32x4*)(yb + yoff_b) = r1; }
+                    if (NH == 2 && row_b >= 0) { *(f32x4*)(yb + yoff_b - 16) = h1; *(f32x4*)(yb + yoff_b) = r1; }
                 } else {
                     if (row_a >= 0) *(f32x4*)(yb + yoff_a) = r0;
-                    if (row_b >= 0) *(f32x4*)(yb + yoff_b) = r1;
+                    if (NH == 2 && row_b >= 0) *(f32x4*)(yb + yoff_b) = r1;
                 }
             }
         }
@@ -355,6 +369,7 @@ __global__ __launch_bounds__(NW * 64, 2) void spmm_split(SplitArgs a) {
 extern "C" int32_t sgp_spmm_split_chunks(void) { return NCH; }
 extern "C" int32_t sgp_spmm_split_max_union(void) { return SMAX; }
 extern "C" int32_t sgp_spmm_split_waves(void) { return NW; }
+extern "C" int32_t sgp_spmm_split_rows_per_wave(void) { return 16 * NH; }
 
 extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
                                   const int32_t* adr,

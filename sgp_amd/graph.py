@@ -258,19 +258,20 @@ class ShiftOperator:
                 from . import hip, splitplan
                 lib = hip.load()
                 lim = dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
-                           max_union=lib.sgp_spmm_split_max_union())
+                           max_union=lib.sgp_spmm_split_max_union(), rows_per_wave=lib.sgp_spmm_split_rows_per_wave())
                 args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
                 plan = splitplan.build_split_plan(*args, **lim)
                 # numberings without locality (32 consecutive rows share no columns): deal the rows in a
                 # locality order of the graph itself, as the tile plans do
-                if plan is not None and plan.stats["rows_per_wave"] < 24 and self.num_nodes >= 2048 and \
+                if plan is not None and plan.stats["rows_per_wave"] < 0.75 * lim["rows_per_wave"] and self.num_nodes >= 2048 and \
                         self.num_cols == self.num_nodes:
                     alt = splitplan.build_split_plan(*args, order=locality_order(
                         self.rowptr.numpy(), self.col.numpy(), self.num_nodes), **lim)
                     if alt is not None and alt.stats["staged_per_row"] < plan.stats["staged_per_row"]:
                         plan = alt
                 # a plan that stages many rows per result row (no locality at all) loses to the other kernels
-                if plan is not None and (plan.stats["rows_per_wave"] < 12 or plan.stats["staged_per_row"] > 8):
+                if plan is not None and (plan.stats["rows_per_wave"] < 0.375 * lim["rows_per_wave"] or
+                                         plan.stats["staged_per_row"] > 8):
                     plan = None
                 if plan is not None:
                     plan = plan.to(device)

@@ -115,6 +115,7 @@ SIGNATURES = {
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
     "sgp_spmm_split_waves": (c_i32, []),
+    "sgp_spmm_split_rows_per_wave": (c_i32, []),
     "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64,
                                              c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
                                              c_i32, c_i32, c_i32, c_i32, c_p]),

@@ -5,7 +5,7 @@ Rows are dealt in order to WAVES of at most 32 rows whose entries touch at most 
 columns, waves to TILES of at most ``waves`` waves whose rows touch at most ``max_union`` distinct columns
 (the tile's staged rows).  Per tile the kernel reads
 
-* ``hdr[tile]``            32 ints: rows of every wave at [8:16], staged rows U at [16]
+* ``hdr[tile]``            64 ints: rows of every wave at [waves : 2 waves], staged rows U at [2 waves]
 * ``rowid[tile, w, slot]``  result row of slot ``16 half + m`` of wave w, -1 = empty slot (rows are dealt in the
                            given numbering or, for numberings without locality, in ``order``)
 * ``ucol[tile, s]``        column (= source row) staged at position s, -1 beyond U
@@ -98,7 +98,7 @@ def split_fp16(v):
     return hi, lo
 
 
-def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768, order=None):
+def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768, order=None, rows_per_wave=32):
     """``order``: optional permutation of the rows (a locality order of the graph): rows are dealt to waves in
     that sequence while the plan keeps addressing rows and columns by their ORIGINAL ids, so no tensor is
     ever permuted."""
@@ -107,7 +107,9 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     val = np.asarray(val, dtype=np.float32)
     if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
         return None
-    deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, order=order)
+    assert rows_per_wave in (16, 32)
+    nh = rows_per_wave // 16                                            # 16-row halves per wave
+    deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=rows_per_wave, order=order)
     if deal is None:
         return None
     wave_of_row, slot_of_row, tile_of_wave, rows = deal
@@ -150,18 +152,18 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     pos = pos_of_key[winv]
     slot = slot_of_row[row_of_edge]
     k = pos % 32
-    dense = np.zeros((n_waves, chunks, 2, 64, 8), dtype=np.float32)      # [wave, chunk, half, lane, e]
+    dense = np.zeros((n_waves, chunks, nh, 64, 8), dtype=np.float32)     # [wave, chunk, half, lane, e]
     np.add.at(dense, (e_wave, pos // 32, slot // 16, (slot % 16) + 16 * (k // 8), k % 8), val)
     amax = float(np.abs(dense).max())                                    # after the duplicates were summed
     w_scale = float(2.0 ** np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
     hi, lo = split_fp16(dense * np.float32(w_scale))
-    afr = np.zeros((n_tiles, waves, chunks, 4, 64, 8), dtype=np.float16)
+    afr = np.zeros((n_tiles, waves, chunks, 2 * nh, 64, 8), dtype=np.float16)
     afr[tile_of_wave, w_in_tile, :, 0::2] = hi
     afr[tile_of_wave, w_in_tile, :, 1::2] = lo
 
-    hdr = np.zeros((n_tiles, 32), dtype=np.int32)
+    hdr = np.zeros((n_tiles, 64), dtype=np.int32)
     hdr[tile_of_wave, waves + w_in_tile] = rows
-    rowid = np.full((n_tiles, waves, 32), -1, dtype=np.int32)
+    rowid = np.full((n_tiles, waves, rows_per_wave), -1, dtype=np.int32)
     all_rows = np.arange(n_rows)
     rowid[tile_of_wave[wave_of_row], w_in_tile[wave_of_row], slot_of_row] = all_rows
     hdr[:, 2 * waves] = union
@@ -193,7 +195,7 @@ def plan_matrix(plan, n_rows, n_cols):
                         src_lane = 16 * g + 4 * i4                      # any lane with i / 4 == i4
                         a_ = int(adr[t, w, c, j, src_lane])
                         s = (a_ // 512) * 8 + (a_ % 512) // 32
-                        for half in range(2):
+                        for half in range(afr.shape[3] // 2):
                             v = afr[t, w, c, 2 * half, lane, e] + afr[t, w, c, 2 * half + 1, lane, e]
                             if v != 0.0:
                                 out[int(rowid[t, w, 16 * half + m]), int(ucol[t, s])] += v / plan.w_scale

@@ -28,7 +28,7 @@ def _check_limits(plan, n_rows, waves=8, chunks=9, max_union=768):
     rowid = plan.rowid.numpy()
     assert sorted(rowid[rowid >= 0].tolist()) == list(range(n_rows))
     assert ((rowid >= 0).sum(2) == cnt).all()
-    assert ((rowid >= 0) == (np.arange(32) < cnt[:, :, None])).all()
+    assert ((rowid >= 0) == (np.arange(rowid.shape[2]) < cnt[:, :, None])).all()
     ucol = plan.ucol.numpy()
     for t in range(plan.n_tiles):
         u = int(union[t])
@@ -121,3 +121,15 @@ def test_locality_order_serves_scrambled_numberings():
     _check_limits(plan, n)
     dense = op.to_dense().numpy().astype(np.float64)
     assert np.abs(splitplan.plan_matrix(plan, n, n) - dense).max() <= 2.0 ** -21 * dense.max()
+
+
+def test_sixteen_waves_of_sixteen_rows():
+    """The other build shape of the kernel: 16 waves x 16 rows (one 16-row half per wave, 8 chunks)."""
+    ei, ew, _ = synthetic.knn_graph(900, 40, seed=5)
+    op = _op(ei, ew, 900)
+    plan = _plan(op, waves=16, chunks=8, rows_per_wave=16)
+    assert plan is not None and plan.rowid.shape[1:] == (16, 16) and plan.afr.shape[1:4] == (16, 8, 2)
+    hdr = plan.hdr.numpy()
+    assert hdr[:, 16:32].max() <= 16 and int(hdr[:, 16:32].sum()) == 900 and hdr[:, 32].max() <= 768
+    dense = op.to_dense().numpy().astype(np.float64)
+    assert np.abs(splitplan.plan_matrix(plan, 900, 900) - dense).max() <= 2.0 ** -21 * dense.max()

@@ -147,6 +147,15 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
                       f"{w['T']} steps, best of 3 per thread setting"}
 
 
+def RESERVOIR_ARITHMETIC(R, F):
+    """What sgp_reservoir_f32 computes with for this layer shape (include/sgp_amd.h)."""
+    from sgp_amd import tune
+    if R in (32, 64) and F in (16, 32, 64) and tune.get("res_bf3", 1, int) != 0:
+        return ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
+                "-- error vs fp64 equal to a CPU fp32 run's")
+    return "exact fp32 MFMA"
+
+
 HOP_ARITHMETIC = {
     "spmm_split": "operands as two fp16 pieces of the scaled value (22 bits), products hi*hi + hi*lo + lo*hi on "
                   "v_mfma_f32_16x16x32_f16, fp32 accumulation; max |error| vs fp64 ~1e-7 of the operand scale "
@@ -426,10 +435,13 @@ def main():
             traffic, source = profiled_traffic(args.workload, kernel)
             if traffic is not None and pieces > 1:
                 traffic /= pieces                          # (profiled per launch of the same size)
+            res_arith = RESERVOIR_ARITHMETIC(R, F) if L == 1 else "exact fp32 MFMA"
             if kernel == "spmm_split":
                 rec["dtype"] = ("f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per "
                                 "product, fp32 accumulation -- agrees with fp32 to ~1e-7 of the operand scale; "
-                                "reservoir: exact fp32 MFMA)")
+                                "reservoir: " + res_arith + ")")
+            elif res_arith != "exact fp32 MFMA":
+                rec["dtype"] = "f32 (hop products: exact fp32; reservoir: " + res_arith + ")"
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                "traffic": traffic, "traffic_source": source,

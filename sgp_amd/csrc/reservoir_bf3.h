@@ -90,7 +90,7 @@ __host__ __device__ constexpr int bf3_unit_kb(int JT, int NKX, int u) {
 }
 
 // experiment switches (build with -DSGP_BF3_ABL=bits): 1 no MFMAs, 2 no piece conversion, 4 no activation,
-// 8 no stores, 16 input rows loaded once
+// 8 no stores, 16 input rows loaded once, 32 no weight-fragment reads
 #ifndef SGP_BF3_ABL
 #define SGP_BF3_ABL 0
 #endif
@@ -103,13 +103,14 @@ __device__ __forceinline__ void bf3_for(F&& f) {
 }
 // weight fragments are read by hand (the compiler would put every ds_read in front of an s_waitcnt lgkmcnt(0))
 template <int OFF> __device__ __forceinline__ void bf3_rd(u32x4& d, unsigned addr) {
+    if constexpr (bf3_abl(32)) { asm volatile("" : "=v"(d) : "v"(addr)); return; }
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF));
 }
 template <int N> __device__ __forceinline__ void bf3_wait(u32x4& a, u32x4& b) {
     asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N));
 }
 __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
-    if constexpr (bf3_abl(1)) { acc[0] += __builtin_bit_cast(float, w[0] ^ v[0]); return acc; }
+    if constexpr (bf3_abl(1)) { asm volatile("" : "+v"(acc) : "v"(w), "v"(v)); return acc; }
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
 }
 
@@ -134,8 +135,11 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
     int tile0, tile1;                                        // the deal of reservoir_layer
     if (a.tiles_per_wave > 0) {
         const int per = a.tiles_per_wave;
-        const int wl = threadIdx.x >> 6, c = wl & 3, k = wl >> 2;
-        const int base = per >> 2, extra = per & 3;
+        // waves c, c + 4, c + 8, .. of the workgroup share SIMD c and its `per` consecutive tiles; the workgroup has just as
+        // many waves per SIMD as deal them evenly (per = 6: three waves of two tiles, not 2 + 2 + 1 + 1 -- a wave with
+        // one tile runs ahead, finishes at half time and leaves the SIMD to two waves)
+        const int wl = threadIdx.x >> 6, c = wl & 3, k = wl >> 2, wps = blockDim.x >> 8;
+        const int base = per / wps, extra = per % wps;
         tile0 = (blockIdx.x * 4 + c) * per + k * base + min(k, extra);
         tile1 = min(tile0 + base + (k < extra ? 1 : 0), a.n_tiles);
     } else {
@@ -260,7 +264,8 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
                 }
-                // leak + store
+                // leak + store (64 bytes of each of 16 rows per instruction.  Swapping pieces between lanes n and n + 8 so
+                // that an instruction writes 8 whole 128-byte lines was measured: no gain, 3.60 vs 3.45-3.6 ms)
                 char* op = reinterpret_cast<char*>(a.out + (long long)t * a.oss);
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt) {

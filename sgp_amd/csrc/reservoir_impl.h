@@ -999,6 +999,8 @@ int launch_layer(ResArgs a, hipStream_t s) {
             m.N = (int)n16;
             m.n_tiles = (int)(n16 / 16);
             if (a.tiles_per_wave <= 0 && m.n_tiles <= 1024) grid = m.n_tiles;
+            // as many waves per SIMD as share its tiles evenly (6 tiles: 3 waves of 2; same time as 2 + 2 + 1 + 1 on 4)
+            if (a.tiles_per_wave > 0) wpw = 4 * ((a.tiles_per_wave + NT - 1) / NT);
             hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)bytes, s, m);
             int rc = sgp::check_launch("reservoir_layer_bf3");
             if (rc || n16 == a.N) return rc;

@@ -48,6 +48,22 @@ unsigned* sync_slot(hipStream_t s) {
     if (hipMemsetAsync(p, 0, kSlotBytes, s) != hipSuccess) return nullptr;
     return reinterpret_cast<unsigned*>(p);
 }
+SideLane* side_lane() {
+    constexpr int kDevs = 64;
+    thread_local SideLane lanes[kDevs] = {};
+    thread_local bool made[kDevs] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kDevs) return nullptr;
+    if (!made[dev]) {
+        SideLane l{};
+        if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&l.forked, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        lanes[dev] = l;
+        made[dev] = true;
+    }
+    return &lanes[dev];
+}
 }  // namespace sgp
 
 extern "C" {

@@ -24,6 +24,17 @@ long tune(const char* key, long dflt);
 // slots come from a per-device ring of 64, cleared on the launch stream, so launches in flight on different
 // streams never share a counter.  nullptr when the allocation fails (callers then run unpaced).
 unsigned* sync_slot(hipStream_t s);
+// A second lane beside the caller's stream (per host thread and device, created on first use): work forked onto
+// `stream` after fork(main) runs concurrently with what the caller enqueues on `main` next; join(main) makes `main`
+// wait for it.  Both are event edges (legal under stream capture).  nullptr when the lane cannot be created.
+struct SideLane {
+    hipStream_t stream;
+    hipEvent_t forked, done;
+    bool fork(hipStream_t main) { return hipEventRecord(forked, main) == hipSuccess && hipStreamWaitEvent(stream, forked, 0) == hipSuccess; }
+    bool join(hipStream_t main) { return hipEventRecord(done, stream) == hipSuccess && hipStreamWaitEvent(main, done, 0) == hipSuccess; }
+};
+SideLane* side_lane();
+
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -1071,14 +1071,26 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
             ResArgs m = a;
             m.N = left ? per * 1024 * 16 : a.N;
             m.tiles_per_wave = per;
-            int rc = per > 4 ? launch_layer<JT, NKX, 2>(m, s) : launch_layer<JT, NKX, 1>(m, s);
-            if (rc || !left) return rc;
+            if (!left) return per > 4 ? launch_layer<JT, NKX, 2>(m, s) : launch_layer<JT, NKX, 1>(m, s);
             ResArgs t = a;
             const long long n0 = (long long)per * 1024 * 16;
             t.x = a.x + n0 * a.xrs;
             t.out = a.out + n0 * a.ors;
             if (a.h_state) t.h_state = a.h_state + n0 * a.R;
             t.N = a.N - (int)n0;
+            // the tail is a chain of T short steps on `left` <= 512 workgroups (1.3 ms per 1024 steps whatever their
+            // number): it goes onto a side lane and runs beside the main part (its workgroups fit next to the main
+            // part's one workgroup per CU: 4 waves and ~50 KB of LDS each)
+            static const int beside = (int)sgp::tune("res_tail_beside", 1);
+            sgp::SideLane* lane = beside ? sgp::side_lane() : nullptr;
+            if (lane && lane->fork(s)) {
+                int rc_t = launch_splitj<JT, NKX>(t, left, lane->stream);
+                int rc = per > 4 ? launch_layer<JT, NKX, 2>(m, s) : launch_layer<JT, NKX, 1>(m, s);
+                if (!lane->join(s)) return sgp::fail(SGP_EINVAL, "reservoir: side lane join failed");
+                return rc ? rc : rc_t;
+            }
+            int rc = per > 4 ? launch_layer<JT, NKX, 2>(m, s) : launch_layer<JT, NKX, 1>(m, s);
+            if (rc) return rc;
             return launch_splitj<JT, NKX>(t, left, s);
         }
     }

@@ -150,7 +150,7 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
 def RESERVOIR_ARITHMETIC(R, F):
     """What sgp_reservoir_f32 computes with for this layer shape (include/sgp_amd.h)."""
     from sgp_amd import tune
-    if R in (32, 64) and F in (16, 32, 64) and tune.get("res_bf3", 1, int) != 0:
+    if ((R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128))) and tune.get("res_bf3", 1, int) != 0:
         return ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
                 "-- error vs fp64 equal to a CPU fp32 run's")
     return "exact fp32 MFMA"

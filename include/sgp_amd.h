@@ -256,8 +256,9 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  *   (weights re-laid out in MFMA fragment order); contents need not persist.
  * Multi-layer reservoirs (reservoir.py:174-176) are run layer by layer: layer
  * l > 0 reads layer l-1's slot of the output as its x.
- * Arithmetic: fp32 products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 accumulation.  Narrow layers
- * (R = 32 or 64 with F = 16, 32 or 64, 16-byte aligned rows) take csrc/reservoir_bf3.h instead: every operand as
+ * Arithmetic: fp32 products on the fp32 matrix cores (v_mfma_f32_16x16x4_f32), fp32 accumulation.  Layers with
+ * R = 32 or 64 and F = 16, 32 or 64, and large layers with R = 256 and F = 32, 64 or 128 (16-byte aligned rows)
+ * take csrc/reservoir_bf3.h instead: every operand as
  * three bf16 pieces (24 bits, no scale, no bound on the values), six piece products per product on
  * v_mfma_f32_16x16x32_bf16, fp32 accumulation -- as close to the fp64 result as a CPU fp32 evaluation
  * (tests/test_gpu_reservoir_bf3.py); SGP_TUNE=res_bf3=0 keeps the fp32 matrix cores for them too.

@@ -82,6 +82,33 @@ __global__ void pack_weights_bf3(const float* __restrict__ w_ih, const float* __
 }
 
 
+// streamed layout of the wide reservoirs: one thread per (sub-block = 2 k-block + half, tile of the half, lane)
+__global__ void pack_weights_sbf3(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                  const float* __restrict__ b, char* __restrict__ out, int F, int R, int JT, int NKX) {
+    const int KBH = JT / 2, KBX = NKX / 8, NSB = 2 * (KBH + KBX);     // input k-blocks first
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < JT * 16) reinterpret_cast<float*>(out)[i] = i < R ? b[i] : 0.f;
+    if (i >= NSB * 8 * 64) return;
+    const int l = i & 63, j8 = (i >> 6) & 7, sb = i >> 9;
+    const int kb = sb >> 1, jt = 8 * (sb & 1) + j8;
+    const int j = 16 * jt + (l & 15), g = l >> 4;
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (kb >= KBX) {
+            const int k = 16 * (2 * (kb - KBX) + (s >> 2)) + 4 * g + (s & 3);
+            w[s] = (j < R && k < R) ? w_hh[(long long)j * R + k] : 0.f;
+        } else {
+            const int k = bf3_feature(NKX, g, 8 * kb + s);
+            w[s] = (j < R && k < F) ? w_ih[(long long)j * F + k] : 0.f;
+        }
+    }
+    u32x4 p1, p2, p3;
+    bf3_split8(w, p1, p2, p3);
+    u32x4* o = reinterpret_cast<u32x4*>(out + 1024) + ((long long)(sb * 8 + j8) * 3) * 64 + l;
+    o[0] = p1; o[64] = p2; o[128] = p3;
+}
+
 long long bf3_offset(int jt, int nkx) { return (packed_floats(jt, nkx) * 4 + 255) / 256 * 256; }
 
 int pick_nkx(int F) {
@@ -106,7 +133,8 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     const int jt = pick_jt(R), nkx = pick_nkx(F);
     if (!jt || !nkx) return -1;
     // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
-    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0);
+    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
+           (sbf3_supported(jt, nkx) ? sbf3_packed_bytes(jt, nkx) + 1024 : 0);     // + dump area of the kernel
 }
 
 int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
@@ -143,6 +171,14 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
         const int threads = jt * (bf3_kbh(jt) + bf3_kbx(nkx)) * 64;
         hipLaunchKernelGGL(pack_weights_bf3, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wb, F, R, jt, nkx);
         rc = sgp::check_launch("pack_weights_bf3");
+        if (rc) return rc;
+        a.wp_bf3 = wb;
+    }
+    if (use_bf3 && sbf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) {
+        char* wb = (char*)workspace + bf3_offset(jt, nkx);
+        const int threads = 2 * (jt / 2 + nkx / 8) * 8 * 64;
+        hipLaunchKernelGGL(pack_weights_sbf3, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wb, F, R, jt, nkx);
+        rc = sgp::check_launch("pack_weights_sbf3");
         if (rc) return rc;
         a.wp_bf3 = wb;
     }

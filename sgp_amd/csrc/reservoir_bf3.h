@@ -42,6 +42,13 @@ __host__ __device__ constexpr bool bf3_supported(int JT, int NKX) {
 }
 
 
+// wide reservoirs (reservoir_layer_stream_bf3, reservoir_impl.h): bias [256] fp32, then per (k-block, half of the
+// output tiles) 8 tiles x 3 pieces x 64 lanes x 16 bytes -- the order the kernel streams them through the LDS
+__host__ __device__ constexpr bool sbf3_supported(int JT, int NKX) { return JT == 16 && NKX % 8 == 0 && NKX <= 32; }
+__host__ __device__ constexpr long long sbf3_packed_bytes(int JT, int NKX) {
+    return 1024 + 2ll * (JT / 2 + NKX / 8) * 8 * 3 * 1024;
+}
+
 // input feature held by lane group q in its register ks
 __host__ __device__ constexpr int bf3_feature(int NKX, int q, int ks) {
     return NKX % 4 == 0 ? 16 * (ks >> 2) + 4 * q + (ks & 3) : q * NKX + ks;

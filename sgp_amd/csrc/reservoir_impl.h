@@ -700,6 +700,199 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream8(ResArgs a) {
     }
 }
 
+// ---- wide reservoirs on the 16-bit matrix cores: the three-piece bf16 products of reservoir_bf3.h with the weight
+// fragments streamed through the LDS as above.  A step's fragments -- [k-block][half of the output tiles][tile][3
+// pieces][64 lanes][16 B], 24 KB per sub-block (k-block, half), input k-blocks first -- pass through a ring of 4 slots;
+// each of the 8 waves fetches 3 KB of every slot by LDS-DMA and multiplies its own node tile against all of it.  The
+// state's pieces are cut once per k-block (36 VALU instructions), the chains of two output tiles alternate on the matrix
+// pipe: 1152 MFMAs of 17 cycles per tile and step instead of 1536 of 32.
+// Memory: a CU moves 24 KB of rows per tile and step (8 KB in, 16 KB out) through a path that turns ~7-10 B/clk around --
+// a quarter of the step if the step waits for it.  So nothing waits: the state of step t - 1 is stored one 1-KB piece
+// per sub-block DURING step t (the registers hold it until the end of step t anyway), the input rows of step t + 1 are
+// requested one piece per sub-block once the input k-blocks of step t are done, and every s_waitcnt counts exactly the
+// operations issued since the fetch it needs (all loads and stores unconditional: lanes without a node read row 0 and
+// store to a dump area behind the packed weights).
+template <int JT, int NKX>
+__global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) {
+    static_assert(sbf3_supported(JT, NKX), "stream bf3 kernel: R = 256, F = 32 .. 128");
+    constexpr int RING = 4, AHEAD = 3;
+    constexpr int KBH = JT / 2, KBX = NKX / 8, NSB = 2 * (KBH + KBX);    // sub-blocks per step: (k-block, half), input first
+    constexpr int NXL = NKX / 4;                         // 16-byte input loads per lane and step
+    constexpr int SLOT = 8 * 3 * 1024;                   // bytes per sub-block
+    constexpr int PPW = 3;                               // 1-KiB pieces of a sub-block per wave
+    static_assert(NSB >= JT && 2 * KBX + NXL <= NSB, "one store / one load per sub-block");
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* bias_l = lds + RING * SLOT / 4;               // after the ring slots
+    const char* wpb = static_cast<const char*>(a.wp_bf3);
+    for (int i = threadIdx.x; i < JT * 16; i += 512) bias_l[i] = reinterpret_cast<const float*>(wpb)[i];
+
+    const int lane = threadIdx.x & 63;
+    const int n_in = lane & 15, q = lane >> 4;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // tile assignment of reservoir_layer_stream8: full workgroups own 8 tiles, the tail ones 4 (waves 0-3)
+    const int full = a.tiles_per_wave;
+    int tile0, tile1;
+    if ((int)blockIdx.x < full) { tile0 = (int)blockIdx.x * 8 + wv; tile1 = tile0 + 1; }
+    else { tile0 = full * 8 + ((int)blockIdx.x - full) * 4 + wv; tile1 = wv < 4 ? tile0 + 1 : tile0; }
+    tile1 = min(tile1, a.n_tiles);
+    const bool busy = tile0 < tile1;                     // wave-uniform: this wave owns a tile
+    const int node = tile0 * 16 + n_in;
+    const bool ok = busy && node < a.N;
+    float* const dump = reinterpret_cast<float*>(const_cast<char*>(wpb) + sbf3_packed_bytes(JT, NKX)) + lane * 4;
+    const float* const xrow = a.x + (long long)(ok ? node : 0) * a.xrs + 4 * q;
+    float* const orow = a.out + (long long)(ok ? node : 0) * a.ors + 4 * q;
+
+    f32x4 h[JT];
+#pragma unroll
+    for (int jt = 0; jt < JT; ++jt) {
+        h[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.h_state && ok) h[jt] = *reinterpret_cast<const f32x4*>(a.h_state + (long long)node * a.R + 16 * jt + 4 * q);
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    const unsigned voff = (unsigned)lane * 16u;
+    const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PPW * wv) * 1024u);
+    const char* src_w = wpb + 1024 + (long long)(PPW * wv) * 1024;
+    auto fetch_piece = [&](int sb, int pos, int p) {     // this wave's piece p of sub-block sb into ring position pos
+        const char* sp = src_w;
+        unsigned l0 = lds_w;
+        asm volatile("" : "+s"(sp), "+s"(l0));
+        const unsigned slot = l0 + (unsigned)(pos & (RING - 1)) * SLOT;
+        if constexpr (bf3_abl(64)) return;               // experiment: no weight stream
+        res_dma16(sp + (long long)sb * SLOT + p * 1024, voff, slot + (unsigned)p * 1024u);
+    };
+    auto fetch = [&](int sb, int pos) {
+#pragma unroll
+        for (int p = 0; p < PPW; ++p) fetch_piece(sb, pos, p);
+    };
+    // input rows: register 4 k4 + s <-> feature 16 k4 + 4 q + s (bf3_feature); loaded by hand so that the compiler
+    // puts no s_waitcnt of its own between the counted ones
+    f32x4 xr[NXL];
+    auto load_x = [&](int k4, int t) {
+        const float* p = xrow + (long long)t * a.xss + 16 * k4;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(xr[k4]) : "v"(p) : "memory");
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // initial-state loads retired
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < AHEAD; ++b) fetch(b, b);
+#pragma unroll
+    for (int k4 = 0; k4 < NXL; ++k4) load_x(k4, 0);
+    int cnt = 0;                                         // sub-blocks consumed so far (ring position of the next one)
+    // Sub-block sb + 1 is complete in the LDS before the MFMAs of sub-block sb start (barrier at the top of sb), so the
+    // first fragments of sb + 1 are read under the last MFMAs of sb instead of behind the barrier with the pipe idle.
+    u32x4 f[6];
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 6; ++k) f[k] = (reinterpret_cast<const u32x4*>(lds) + lane)[k * 64];
+
+    // memory operations a wave issues in sub-block sb, after its barrier: the 3 DMA pieces of sub-block sb + 3, one
+    // 16-byte-per-lane store of the state of the step before (sb < JT), one input load for the next step
+    auto ops = [](int sb) constexpr { return PPW + (sb < JT ? 1 : 0) + (sb >= 2 * KBX && sb < 2 * KBX + NXL ? 1 : 0); };
+
+    for (int t = 0; t <= a.T; ++t) {                     // iteration T only stores the last state
+        f32x4 acc[JT];
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt) acc[jt] = *reinterpret_cast<const f32x4*>(bias_l + jt * 16 + q * 4);
+        float* const op = (ok && t > 0) ? orow + (long long)(t - 1) * a.oss : dump;      // rows of step t - 1
+        const bool real = t < a.T;
+        const int tn = t + 1 < a.T ? t + 1 : (a.T > 0 ? a.T - 1 : 0);                     // rows to request: step t + 1
+        u32x4 v1, v2, v3;
+        static_for<0, NSB>([&](auto sc) {
+            constexpr int sb = decltype(sc)::value, blk = sb / 2, half = sb % 2;
+            // sub-block sb + 1 (requested two sub-blocks ago, its last piece the last memory operation of that
+            // sub-block) must have landed: what may still be in flight is what the sub-block before this one issued
+            constexpr int allowed = ops((sb + NSB - 1) % NSB);
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(allowed) : "memory");
+            if constexpr (sb < JT) *reinterpret_cast<f32x4*>((ok && t > 0) ? op + 16 * sb : op) = h[sb];
+            if constexpr (sb >= 2 * KBX && sb < 2 * KBX + NXL) load_x(sb - 2 * KBX, tn);
+            // the pieces of sub-block sb + 3 go into the slot of sub-block sb - 1, which every wave has left; a busy
+            // wave requests them one per pair of output tiles INSIDE its MFMA phase (an issue that stalls on a full
+            // memory queue then waits under queued matrix work, not in front of it)
+            const int fsb = (sb + AHEAD) % NSB, fpos = cnt + AHEAD;
+            if (!(busy && real)) fetch(fsb, fpos);
+            const u32x4* slot = reinterpret_cast<const u32x4*>(lds + (cnt & (RING - 1)) * (SLOT / 4)) + lane;
+            ++cnt;
+            const u32x4* next_slot = reinterpret_cast<const u32x4*>(lds + (cnt & (RING - 1)) * (SLOT / 4)) + lane;
+            if (busy && real) {
+                if constexpr (half == 0) {               // the pieces of a new k-block
+                    float v[8];
+                    if constexpr (blk < KBX) {
+                        asm volatile("" : "+v"(xr[2 * blk]), "+v"(xr[2 * blk + 1]));      // (landed: see `allowed`)
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) v[s] = xr[2 * blk + (s >> 2)][s & 3];
+                    } else {
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) v[s] = h[2 * (blk - KBX) + (s >> 2)][s & 3];
+                    }
+                    if constexpr (bf3_abl(2)) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) { v1[d] = __builtin_bit_cast(unsigned, v[2 * d]); v2[d] = __builtin_bit_cast(unsigned, v[2 * d + 1]); v3[d] = v1[d] ^ v2[d]; }
+                    } else {
+                        bf3_split8(v, v1, v2, v3);
+                    }
+                }
+                // fragment (tile j8 of this half, piece pc) = slot[(j8 * 3 + pc) * 64].  Pairs of tiles, their chains
+                // alternating; the leading pieces multiply first, so that each of the six fragment registers is free
+                // for the next pair's piece 6-10 MFMAs before that is used (no second set of registers)
+#pragma unroll
+                for (int jp = 0; jp < 4; ++jp) {
+                    const u32x4* nx = jp + 1 < 4 ? slot + (jp + 1) * 6 * 64 : next_slot;
+                    f32x4& A = acc[8 * half + 2 * jp];
+                    f32x4& B = acc[8 * half + 2 * jp + 1];
+                    A = bf3_mfma(f[0], v3, A); B = bf3_mfma(f[3], v3, B);
+                    A = bf3_mfma(f[0], v2, A); B = bf3_mfma(f[3], v2, B);
+                    A = bf3_mfma(f[0], v1, A); B = bf3_mfma(f[3], v1, B);
+                    if constexpr (!bf3_abl(32)) { f[0] = nx[0]; f[3] = nx[3 * 64]; }
+                    A = bf3_mfma(f[1], v2, A); B = bf3_mfma(f[4], v2, B);
+                    A = bf3_mfma(f[1], v1, A); B = bf3_mfma(f[4], v1, B);
+                    if constexpr (!bf3_abl(32)) { f[1] = nx[64]; f[4] = nx[4 * 64]; }
+                    A = bf3_mfma(f[2], v1, A); B = bf3_mfma(f[5], v1, B);
+                    if constexpr (!bf3_abl(32)) { f[2] = nx[2 * 64]; f[5] = nx[5 * 64]; }
+                    if (jp < PPW) fetch_piece(fsb, fpos, jp);
+                }
+            }
+        });
+        if (busy && real) {
+            if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
+            } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+            } else if (a.act == SGP_ACT_SELF_NORM) {
+                float ss = 0.f;
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ss = fmaf(acc[jt][r], acc[jt][r], ss);
+                ss += __shfl_xor(ss, 16);
+                ss += __shfl_xor(ss, 32);
+                const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
+            }
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    h[jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
+                                                     : leak(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sub-blocks and rows requested ahead of the end
+    if (a.h_state && ok) {
+#pragma unroll
+        for (int jt = 0; jt < JT; ++jt)
+            *reinterpret_cast<f32x4*>(a.h_state + (long long)node * a.R + 16 * jt + 4 * q) = h[jt];
+    }
+}
+
 template <int JT, int NKX>
 int launch_stream(ResArgs a, hipStream_t s) {
     a.n_tiles = (a.N + 15) / 16;
@@ -715,11 +908,15 @@ int launch_stream(ResArgs a, hipStream_t s) {
     // 8 waves x 1 tile (two waves per SIMD) unless SGP_TUNE=res_stream8=0 asks for round 3's 4 waves x 2 tiles
     static const int eight = (int)sgp::tune("res_stream8", 1);
     void (*kern)(ResArgs) = eight ? reservoir_layer_stream8<JT, NKX, true, true> : reservoir_layer_stream<JT, NKX, true, true>;
-    const int bytes = 4 * JT * 1024 + JT * 16 * 4;           // RING slots + bias
+    int bytes = 4 * JT * 1024 + JT * 16 * 4;                 // RING slots + bias
+    bool bf3 = false;
+    if constexpr (sbf3_supported(JT, NKX)) {
+        if (a.wp_bf3) { kern = reservoir_layer_stream_bf3<JT, NKX>; bytes = 4 * 8 * 3 * 1024 + JT * 16 * 4; bf3 = true; }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(kern, dim3(full + tail_wgs), dim3(eight ? 512 : 256), (size_t)bytes, s, a);
+    hipLaunchKernelGGL(kern, dim3(full + tail_wgs), dim3(eight || bf3 ? 512 : 256), (size_t)bytes, s, a);
     return sgp::check_launch("reservoir_layer_stream");
 }
 

@@ -13,8 +13,10 @@ Python layer
     equal_cost_tiles=0|1, equal_cost_q=0.15   experiment: tiles cut for equal cost
 
 Library (integers)
-    res_bf3=1               narrow reservoirs (R = 32 / 64, F = 16 / 32 / 64): products from three bf16 pieces per operand on the
-                            16-bit matrix cores (csrc/reservoir_bf3.h; fp32-grade, no bound on the operands); 0 = exact-fp32 MFMAs
+    res_bf3=1               reservoirs with R = 32 / 64 (F = 16 / 32 / 64) and R = 256 (F = 32 / 64 / 128): products from three bf16
+                            pieces per operand on the 16-bit matrix cores (csrc/reservoir_bf3.h; fp32-grade, no bound on the
+                            operands); 0 = exact-fp32 MFMAs
+    res_tail_beside=1       the split-J tail of a large layer runs on a side lane beside the main part (0: after it)
     spmm_chunk=32           time steps per workgroup of the staged exact kernels
     spmm_variant=1          inner-loop variant of sgp_spmm_tiled_f32
     mix_mode=6, res_cfg=0   launch shapes of sgp_spmm_mix_f32 / sgp_spmm_res_f32

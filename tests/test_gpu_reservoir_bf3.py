@@ -96,3 +96,24 @@ def test_bf3_products_are_exact_for_bf16_representable_operands():
     res.encode_into(x.cuda(), out)
     ref64 = O.reservoir_forward(x[:1, :256], layers_of(res), dtype=torch.float64)      # step 0: state 0, exact operands
     assert float((out[:1, :256].cpu().double() - ref64).abs().max()) < 4e-7
+
+
+@pytest.mark.parametrize("t", [1, 2, 7])
+def test_bf3_wide_reservoir_short_sequences_strided_rows_and_state(t):
+    """R = 256 (fragments streamed through the LDS, reservoir_layer_stream_bf3): the state of a step is stored during
+    the NEXT step's sub-blocks and once more after the last one -- sequences of 1 and 2 steps, output rows inside a
+    wider buffer, ragged last tile, the state handed on through h_state."""
+    hip.require_gpu()
+    torch.manual_seed(t)
+    n, f, r = 2048 * 16 + 16 * 5 + 3, 64, 256
+    res = sgp_amd.Reservoir(f, r, spectral_radius=0.9)
+    x = torch.randn(t + 3, n, f)
+    xg = x.cuda()
+    wide = torch.zeros(t + 3, n, r + 2 * 64, device="cuda")
+    state = torch.zeros(1, n, r, device="cuda")
+    res.encode_into(xg[:t], wide[:t, :, 64:64 + r], state)
+    res.encode_into(xg[t:], wide[t:, :, 64:64 + r], state)
+    assert float(wide[:, :, :64].abs().max()) == 0.0 and float(wide[:, :, 64 + r:].abs().max()) == 0.0
+    out = wide[:, :, 64:64 + r]
+    assert torch.equal(state[0], out[-1])
+    check(out, x, res, "tanh", [0, 5, 16 * 1000 + 3, n - 20, n - 2, n - 1])

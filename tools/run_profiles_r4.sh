@@ -18,5 +18,13 @@ done
 if [ "${SQ:-0}" = 1 ]; then
   SGP_FORCE=split bash tools/run_prof_sq.sh r4_split_sq 128
   cp gpurun_out/prof_r4_split_sq/summary.txt $OUT/spmm_split_T128_sq_summary.txt 2>/dev/null
-  SGP_TUNE=split_abl=256 T=64 timeout 300 python tools/probe_split_abl.py 256 2>&1 | grep -A64 "spmm_split timeline" > $OUT/spmm_split_timeline.txt
+fi
+# per-wave timeline of the split-fp16 hop (ablation build: tools/build_variant.sh abl -DSGP_ABLATION)
+if [ "${TIMELINE:-0}" = 1 ]; then
+  SGP_AMD_LIB=$ROOTD/tools/variants/abl/libsgp_amd.so T=64 timeout 300 python tools/probe_split_abl.py 256 2>&1 | grep -A64 "spmm_split timeline" | head -70 > $OUT/spmm_split_timeline.txt
+fi
+# SQ counters of the bf16-piece reservoir kernels (narrow: target layer; wide: C5 layer)
+if [ "${RES_SQ:-0}" = 1 ]; then
+  bash tools/run_prof_res_sq.sh r4_bf3 res 256; cp gpurun_out/prof_r4_bf3/summary.txt $OUT/res_bf3_sq_summary.txt 2>/dev/null
+  bash tools/run_prof_res_sq.sh r4_sbf3 res256 64; cp gpurun_out/prof_r4_sbf3/summary.txt $OUT/res_stream_bf3_sq_summary.txt 2>/dev/null
 fi

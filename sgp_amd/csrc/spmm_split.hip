@@ -40,11 +40,11 @@ typedef short s8v __attribute__((ext_vector_type(8)));
 using sgp::f32x4;
 
 #ifndef SGP_SPLIT_NW
-#define SGP_SPLIT_NW 8
+#define SGP_SPLIT_NW 16
 #endif
-constexpr int NW = SGP_SPLIT_NW;             // waves per workgroup: 8 (two 16-row halves per wave) or 16 (one)
+constexpr int NW = SGP_SPLIT_NW;             // waves per workgroup: 16 x 16 rows (default), 12 x 16, or 8 x 32 (two 16-row halves)
 constexpr int NH = NW == 8 ? 2 : 1;          // 16-row halves per wave
-static_assert(NW == 8 || NW == 16, "a tile is 256 rows: 8 waves x 32 or 16 waves x 16");
+static_assert(NW == 8 || NW == 12 || NW == 16, "8 waves x 32 rows, or 12 / 16 waves x 16 rows");
 #ifndef SGP_SPLIT_NCH
 #define SGP_SPLIT_NCH (SGP_SPLIT_NW == 8 ? 9 : 8)
 #endif

@@ -1,7 +1,7 @@
 """Host plan of ``sgp_spmm_split_f32`` (include/sgp_amd.h; kernel ``csrc/spmm_split.hip``): the split-fp16
 hop behind ``x = adj @ x`` (reference: lib/sgp_preprocessing.py:200-203).
 
-Rows are dealt in order to WAVES of at most 32 rows whose entries touch at most ``32 * chunks`` distinct
+Rows are dealt in order to WAVES of at most ``rows_per_wave`` (16; 32 in the 8-wave build) rows whose entries touch at most ``32 * chunks`` distinct
 columns, waves to TILES of at most ``waves`` waves whose rows touch at most ``max_union`` distinct columns
 (the tile's staged rows).  Per tile the kernel reads
 

@@ -98,6 +98,43 @@ def split_fp16(v):
     return hi, lo
 
 
+# k-slots of the four 8-row sets a chunk's two transpose reads serve together (lanes 0-31 / 32-63 of each read)
+_SET_SLOTS = np.array([[0, 1, 2, 3, 8, 9, 10, 11], [4, 5, 6, 7, 12, 13, 14, 15],
+                       [16, 17, 18, 19, 24, 25, 26, 27], [20, 21, 22, 23, 28, 29, 30, 31]])
+
+
+def _bank_aware_slots(w_of_key, pos_of_key, stage, n_chunks_total, chunks):
+    """New position (chunk * 32 + k-slot) of every (wave, column) key: same chunk, k-slot chosen so that the rows
+    one LDS cycle reads together lie in different banks where the chunk's rows allow it."""
+    chunk = pos_of_key // 32
+    wc = w_of_key * chunks + chunk
+    res = stage & 7
+    idx = np.arange(wc.size)
+
+    def rank_within(group, *minor):
+        order = np.lexsort(tuple(reversed(minor)) + (group,))
+        g = group[order]
+        first = np.r_[True, g[1:] != g[:-1]]
+        start = np.maximum.accumulate(np.where(first, idx, 0))
+        out = np.empty_like(idx)
+        out[order] = idx - start
+        return out
+
+    rank = rank_within(wc * 8 + res, stage)              # j-th row of its residue in its chunk
+    primary = rank < 4
+    slot = np.full(wc.size, -1, dtype=np.int64)
+    j = rank_within(np.where(primary, wc * 4 + rank, -1), res)       # index inside its set (at most one row per residue)
+    slot[primary] = _SET_SLOTS[rank[primary], j[primary]]
+    occ = np.zeros((n_chunks_total, 32), dtype=bool)
+    occ[wc[primary], slot[primary]] = True
+    extra = ~primary
+    if extra.any():
+        free = np.argsort(occ, axis=1, kind="stable")    # free k-slots of every chunk first, in order
+        e = rank_within(np.where(extra, wc, -1), res, stage)
+        slot[extra] = free[wc[extra], e[extra]]
+    return chunk * 32 + slot
+
+
 def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768, order=None, rows_per_wave=32):
     """``order``: optional permutation of the rows (a locality order of the graph): rows are dealt to waves in
     that sequence while the plan keeps addressing rows and columns by their ORIGINAL ids, so no tensor is
@@ -137,9 +174,23 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     assert int(pos_of_key.max()) < 32 * chunks and int(union.max()) <= max_union
     stage_of_wkey = stage_of_key[np.searchsorted(tkey, tile_of_wave[w_of_key] * n_cols + wkey % n_cols)]
 
-    # addresses: staged row of (wave, chunk, k), 0 for padding
-    srow = np.zeros((n_waves, chunks * 32), dtype=np.int64)
+    # k-slots inside a chunk: a transpose read serves lanes 0-31 and 32-63 in one LDS cycle each, i.e. the 8 staged rows
+    # behind k = {0-3, 8-11}, {16-19, 24-27} (first read of a chunk) and {4-7, 12-15}, {20-23, 28-31} (second) together;
+    # a staged row s covers the 8 banks (s & 7) * 8 .., so a set of 8 rows is conflict-free when their s & 7 differ.
+    # Columns keep their chunk but are dealt to the four sets by residue (the j-th row of a residue goes to set j),
+    # rows beyond four of a residue take what is left; measured on the target graph: 1.83 -> 1.1 LDS cycles per lane group.
+    pos_of_key = _bank_aware_slots(w_of_key, pos_of_key, stage_of_wkey, n_waves * chunks, chunks)
+
+    # addresses: staged row of (wave, chunk, k); padding slots repeat a row of their own set (same address = broadcast)
+    srow = np.full((n_waves, chunks * 32), -1, dtype=np.int64)
     srow[w_of_key, pos_of_key] = stage_of_wkey
+    sets = srow.reshape(n_waves * chunks, 32)[:, _SET_SLOTS]                # [chunk, set, 8]
+    rep = np.where(sets >= 0, sets, np.iinfo(np.int64).max).min(-1, keepdims=True)
+    rep = np.where(rep == np.iinfo(np.int64).max, 0, rep)
+    filled = np.where(sets >= 0, sets, rep)
+    tmp = np.empty((n_waves * chunks, 32), dtype=np.int64)
+    tmp[:, _SET_SLOTS.reshape(-1)] = filled.reshape(n_waves * chunks, 32)
+    srow = tmp.reshape(n_waves, chunks * 32)
     srow = srow.reshape(n_waves, chunks, 4, 2, 4)           # [wave, chunk, g, j, i / 4]: k = 8 g + 4 j + i / 4
     lane_i = np.arange(16)
     sl = srow[:, :, :, :, lane_i >> 2]

@@ -224,23 +224,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
             *(uint2*)(rb + cv_off + i * (NW * 1024) + 256) = lo;
         }
     };
-    // 4 x 4 transpose inside every quad of lanes (two DPP butterfly stages): lane 4 q + j ends up with row
-    // 4 g + j, features 4 q .. 4 q + 3, i.e. one 16-byte piece of a result row -- 2 stores per unit instead of 8
-    auto quad_transpose = [&](f32x4& r) {
-        const bool b0 = lane & 1, b1 = lane & 2;
-        auto swap1 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true)); };
-        auto swap2 = [](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true)); };
-        const float ra = swap1(b0 ? r[0] : r[1]), rb = swap1(b0 ? r[2] : r[3]);
-        const float a0 = b0 ? ra : r[0], a1 = b0 ? r[1] : ra, a2 = b0 ? rb : r[2], a3 = b0 ? r[3] : rb;
-        const float rc = swap2(b1 ? a0 : a2), rd = swap2(b1 ? a1 : a3);
-        r[0] = b1 ? rc : a0; r[1] = b1 ? rd : a1; r[2] = b1 ? a2 : rc; r[3] = b1 ? a3 : rd;
-    };
-    // after the transpose this lane stores row slots my_slot (half 0) and 16 + my_slot (half 1); -1 = empty slot
-    const int my_slot = 4 * (lane >> 4) + (lane & 3);
+    // The products are formed TRANSPOSED -- the staged rows are the MFMA's A operand (M = the slice's 16 features), the
+    // plan's fragments its B operand (N = the wave's 16 rows; both operands have the same lane layout) -- so that the
+    // accumulator of lane (n, q) is features 4 q .. 4 q + 3 of row n: one 16-byte piece of a result row, stored as it is
+    // (before: a 4 x 4 transpose inside every quad of lanes, ~20 VALU instructions per unit and half).
+    // This lane stores row slots my_slot (half 0) and 16 + my_slot (half 1); -1 = empty slot
+    const int my_slot = lane & 15;
     const int* rid = a.rowid + (size_t)(tile * NW + wave) * (16 * NH);
     const int row_a = rid[my_slot], row_b = NH == 2 ? rid[(NH - 1) * 16 + my_slot] : -1;
-    const long long yoff_a = (long long)row_a * a.yrs + 4 * ((lane >> 2) & 3);
-    const long long yoff_b = (long long)row_b * a.yrs + 4 * ((lane >> 2) & 3);
+    const long long yoff_a = (long long)row_a * a.yrs + 4 * (lane >> 4);
+    const long long yoff_b = (long long)row_b * a.yrs + 4 * (lane >> 4);
 
     const int n_units = (t_end - t_begin) * a.nslice;
     // DMA cursor (two units ahead of the multiply) and multiply cursor
@@ -314,18 +307,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
                 else tr_wait<0>(x);
                 const h8 bh = cat8(x.h0, x.h1), bl = cat8(x.l0, x.l1);
                 if constexpr (NH == 2) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1)], bh, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1)], bl, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][2 * (NH - 1) + 1], bh, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][2 * (NH - 1)], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, af[c][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, af[c][2 * (NH - 1)], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][2 * (NH - 1) + 1], acc1, 0, 0, 0);
                 } else {
                     // one half per wave: the cross terms go to a second accumulator so that consecutive MFMAs do
                     // not wait for each other's result (four waves per SIMD fill the rest)
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bh, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][0], bl, acc1, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[c][1], bh, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][0], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, af[c][0], acc1, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc1, 0, 0, 0);
                 }
                 if (c < NLD && dma_now && !late && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024));
             }
@@ -340,8 +333,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
         stamp(u, 4);
         if (!ABL(4)) {
             f32x4 r0 = acc0 * a.inv_scale, r1 = acc1 * a.inv_scale;
-            quad_transpose(r0);
-            if constexpr (NH == 2) quad_transpose(r1);
             // an even slice waits for its odd neighbour: the two 64-byte halves of a 128-byte line leave together
             if (!(sl & 1) && sl + 1 < a.nslice && !ABL(32)) {
                 h0 = r0; h1 = r1;

@@ -197,7 +197,9 @@ int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride
  *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
  *   afr[n_tiles][W][chunks][rows / 8][64][8] fp16   A fragments in lane order (2 * half + piece)
  *   adr[n_tiles][W][chunks][2][64]           per-lane byte address of the transpose reads
- * with W = sgp_spmm_split_waves(), rows = sgp_spmm_split_rows_per_wave() (8 x 32 or 16 x 16: a build parameter),
+ * with W = sgp_spmm_split_waves(), rows = sgp_spmm_split_rows_per_wave() (16 waves x 16 rows by default; 8 x 32 and
+ * 12 x 16 are build parameters), the k-slots of a chunk in any order (the planner picks one that keeps the rows a
+ * transpose read fetches together on different LDS banks),
  * chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0.  X / X_halo /
  * n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows a node partition received).  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
  * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */

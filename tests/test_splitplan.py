@@ -133,3 +133,32 @@ def test_sixteen_waves_of_sixteen_rows():
     assert hdr[:, 16:32].max() <= 16 and int(hdr[:, 16:32].sum()) == 900 and hdr[:, 32].max() <= 768
     dense = op.to_dense().numpy().astype(np.float64)
     assert np.abs(splitplan.plan_matrix(plan, 900, 900) - dense).max() <= 2.0 ** -21 * dense.max()
+
+
+def test_k_slots_keep_the_rows_of_a_transpose_read_on_different_banks():
+    """A ``ds_read_b64_tr_b16`` serves lanes 0-31 and 32-63 in one LDS cycle each: 8 staged rows, each covering
+    the 8 banks ``(s & 7) * 8 ..`` of its position s.  The planner deals a chunk's rows to the four 8-row sets by
+    ``s & 7`` (``_bank_aware_slots``): on a geometric graph the reads must stay close to one cycle per lane group
+    (columns in sorted order: ~1.8), and the plan still is the operator."""
+    n = 6000
+    ei, ew, _ = synthetic.knn_graph(n, 60, seed=3)
+    op = _op(ei, ew, n)
+    plan = _plan(op, waves=16, chunks=8, rows_per_wave=16)
+    adr, hdr = plan.adr.numpy(), plan.hdr.numpy()
+    a = adr[hdr[:, 16:32] > 0]                                 # [wave, chunk, read, lane]
+    s = (a // 512) * 8 + (a % 512) // 32
+    cycles = []
+    for half in range(2):
+        rows = s[..., np.arange(half * 32, half * 32 + 32, 4)]          # the 8 rows one LDS cycle fetches
+        per_bank = np.zeros(rows.shape[:-1], dtype=np.int64)
+        for q in range(8):
+            v = np.sort(np.where((rows & 7) == q, rows, -1), axis=-1)
+            distinct = ((v[..., 1:] != v[..., :-1]) & (v[..., 1:] >= 0)).sum(-1) + (v[..., 0] >= 0)
+            per_bank = np.maximum(per_bank, distinct)
+        cycles.append(per_bank)
+    mean_cycles = float(np.mean(cycles))
+    assert mean_cycles < 1.35, mean_cycles
+    dense = torch.sparse_coo_tensor(torch.stack([torch.repeat_interleave(torch.arange(n), op.rowptr[1:] - op.rowptr[:-1]),
+                                                 op.col.long()]), op.val.double(), (n, n)).to_dense().numpy()
+    got = splitplan.plan_matrix(plan, n, n)
+    assert np.abs(got - dense).max() <= 2.0 ** -21 * np.abs(dense).max()

@@ -177,7 +177,7 @@ def exact_hop_line(op, out, d_h, bts):
             a.record(); op.propagate(src, dst); b.record()
             torch.cuda.synchronize()
             ms.append(a.elapsed_ms(b))
-        kernel = op.last_kernel
+        kernel = op.resolved_kernel()
     finally:
         if saved is None:
             os.environ.pop("SGP_TUNE", None)
@@ -197,7 +197,7 @@ def verify_output(enc, ops, x, out, w, T, tc, d_h):
     K, n_t = w["K"], out.shape[0]
     steps = sorted({s for s in (0, 1, 31, 32, 63, 64, 65, n_t // 2, n_t - 2, n_t - 1) if 0 <= s < n_t})
     idx = torch.tensor(steps, device=out.device)
-    worst, worst_rel = 0.0, 0.0
+    worst, worst_rel, worst_col = 0.0, 0.0, 0.0
     ok = True
     for d, op in enumerate(ops):
         for h in range(K):
@@ -209,8 +209,12 @@ def verify_output(enc, ops, x, out, w, T, tc, d_h):
             err = float((got - ref).abs().max())
             worst = max(worst, err)
             worst_rel = max(worst_rel, float((got - ref).norm() / ref.norm().clamp_min(1e-30)))
-            ok = ok and bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-5))
-    rec = {"hop_blocks_vs_csr_kernel_max_abs": worst, "hop_blocks_rel_fro": worst_rel, "steps_checked": steps}
+            # every feature column on its own (a whole-block norm is dominated by its largest columns)
+            col = (got - ref).flatten(0, 1).norm(dim=0) / ref.flatten(0, 1).norm(dim=0).clamp_min(1e-30)
+            worst_col = max(worst_col, float(col.max()))
+            ok = ok and bool(torch.allclose(got, ref, rtol=1e-5, atol=1e-5)) and float(col.max()) <= 1e-5
+    rec = {"hop_blocks_vs_csr_kernel_max_abs": worst, "hop_blocks_rel_fro": worst_rel,
+           "hop_blocks_worst_column_rel_fro": worst_col, "steps_checked": steps}
     if w["glob"]:
         p = out.shape[2] // d_h - 1
         m = out[idx][:, :, :d_h].mean(1, keepdim=True)
@@ -431,7 +435,7 @@ def main():
             pieces = max(1, round(len(hop_ms) / (args.steps * n_chunks * K * len(ops))))
             bts = hop_bytes(N, tc / pieces, d_h, nnz)
             achieved = bts / (per_launch * 1e-3) / 1e9
-            kernel = getattr(ops[0], "last_kernel", "?")
+            kernel = ops[0].resolved_kernel() if hasattr(ops[0], "resolved_kernel") else getattr(ops[0], "last_kernel", "?")
             traffic, source = profiled_traffic(args.workload, kernel)
             if traffic is not None and pieces > 1:
                 traffic /= pieces                          # (profiled per launch of the same size)
@@ -452,8 +456,8 @@ def main():
                                "ms_min_median_max": [all_ms[0], all_ms[len(all_ms) // 2], all_ms[-1]],
                                "launches_timed": len(all_ms),
                                "arithmetic": HOP_ARITHMETIC.get(kernel, "exact fp32 products (fp32 MFMA / FMA)")}
-            if kernel == "spmm_split" and not args.no_exact_line:
-                rec["roofline_exact_fp32"] = exact_hop_line(ops[0], out, d_h, bts / pieces if pieces > 1 else bts)
+            exact_bts = bts / pieces if pieces > 1 else bts
+            want_exact_line = kernel == "spmm_split" and not args.no_exact_line
         elif timeline:
             # rank 0's GPU: a hop of the local block = its launches over the time chunks; the
             # exchange of a hop = gather + all_to_all on the communication stream
@@ -469,7 +473,7 @@ def main():
             achieved = bts / (hop_t * 1e-3) / 1e9
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                               "kernel": getattr(blk.op, "last_kernel", "?"),
+                               "kernel": blk.op.resolved_kernel() if hasattr(blk.op, "resolved_kernel") else "?",
                                "ms_per_launch": hop_t / launches,
                                "algorithmic_bytes": bts,
                                "scope": "rank 0's local block, per GPU peak"}
@@ -483,9 +487,12 @@ def main():
                                 "note": "comm (row packing + all_to_all on its own stream) runs "
                                         "under the SpMM of the previous time chunk; the reservoir of "
                                         "the next time piece runs under both (third stream)"}
+        # the timed output is verified BEFORE anything else writes to it (the exact-fp32 line below overwrites hop slot 1)
         if world == 1 and spatial is None and not args.no_verify:
             rec["verify"] = verify_output(enc, ops, x, out, w, T, tc, d_h)
             rec["verified"] = bool(rec["verify"]["ok"])
+        if hop_ms and want_exact_line:
+            rec["roofline_exact_fp32"] = exact_hop_line(ops[0], out, d_h, exact_bts)
         if not args.no_cpu_baseline and world == 1:
             rec["cpu_baseline"] = cpu_baseline(w, ei, ew)
         os.write(json_fd, (json.dumps(rec) + "\n").encode())

@@ -42,7 +42,10 @@
 extern "C" {
 #endif
 
-#define SGP_ABI_VERSION 1
+/* 2 (round 5): sgp_spmm_split_f32 takes per-column scale tables and a per-row plan array; sgp_col_stats_f32,
+ * sgp_split_prepare_f32, sgp_launch_predicate added; round 4 had already removed sgp_spmm_mfma / pipe / blk_*, widened
+ * sgp_spmm_colblock_f32 by the halo arguments and grown sgp_reservoir_workspace_bytes (bf16-piece fragments). */
+#define SGP_ABI_VERSION 2
 
 #define SGP_EINVAL   (-1)  /* bad size / null pointer / misaligned stride */
 #define SGP_EUNSUP   (-2)  /* shape outside what the kernels are built for */
@@ -186,34 +189,73 @@ int32_t sgp_spmm_mix_max_dense(int32_t halo);
 int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                     int32_t n_rows, int32_t batch, int32_t feat, float* out, sgp_stream_t stream);
 
+/* Launch predicate: the NEXT hop launch (sgp_spmm_*_f32) of the calling host thread runs only if *flag == run_if
+ * when its kernel starts on the stream, and is a no-op otherwise; the setting is consumed by that one call.  This is
+ * how a hop chooses between the split-fp16 kernel and the exact-fp32 kernels ON THE DEVICE: sgp_split_prepare_f32
+ * writes the flag, the caller enqueues sgp_spmm_split_f32 with run_if = 1 and its exact kernel with run_if = 0
+ * (no host round trip, legal under stream capture).  flag = NULL clears it. */
+int sgp_launch_predicate(const int32_t* flag, int32_t run_if);
+
+/* Per-column statistics of a strided [batch, n_rows, feat] view over the steps 0, t_stride, 2 t_stride, ...:
+ * stats[0 : feat] = max |x[:, c]| (bit pattern of the float; NaN / inf win), stats[feat : 2 feat] = sum of
+ * squares.  accumulate = 0 clears stats first; 1 adds a second source (the halo rows of a node partition) to it.
+ * feat % 4 == 0, feat <= 1024, 16-byte aligned rows. */
+int sgp_col_stats_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                      int32_t n_rows, int32_t batch, int32_t feat, int32_t t_stride, int32_t accumulate,
+                      float* stats, sgp_stream_t stream);
+
+/* Scales, next bound and admission flag of the split-fp16 hop, on the device.  Per column c the bound B_c >= max
+ * |x[:, c]| is bound_in[c] (device) if given, else bound_scalar if > 0, else the measured maximum (needs full = 1:
+ * statistics over EVERY row).  An a-priori bound is never replaced by a measurement: the scales of a bounded operand
+ * do not depend on how the caller cuts the time axis (bit-identical results per time chunk).  x_tab[c] = 2^e with
+ * B_c 2^e in [2^13, 2^14] (B_c = 0: scale 1, the column is identically zero), x_tab[feat + c] = 2^-e,
+ * bound_out[c] = B_c * norm_inf * (1 + 1e-6) (the bound of A x for ||A||_inf = norm_inf; may be NULL).
+ * flag[0] = 1 iff every bound is finite, covers the sampled data, and -- when statistics are given -- satisfies
+ *     B_c * sqrt(s_eff) <= 2^16 * sqrt(ssq_c / n_samples)           for every column with B_c > 0
+ * (n_samples = rows behind the sums, s_eff = rows of the operand / rows sampled >= 1: a strided sample overstates a
+ * mean square by at most that factor).  Why: the split kernel represents |x| >= 2^-16 B_c to 2^-23 relative and
+ * everything smaller to 2^-38 B_c ABSOLUTE; the test keeps that absolute term below 2^-22 of the column's RMS,
+ * i.e. at fp32's own level.  stats = NULL: no test, the caller vouches for the bound (flag = bounds finite). */
+int sgp_split_prepare_f32(const float* stats, double n_samples, double s_eff, int32_t full,
+                          const float* bound_in, float bound_scalar, float norm_inf, int32_t feat,
+                          float* x_tab, float* bound_out, int32_t* flag, sgp_stream_t stream);
+
 /* Split-fp16 hop (lib/sgp_preprocessing.py:200-203, `x = adj @ x` per hop; plan: sgp_amd/splitplan.py;
  * kernel: csrc/spmm_split.hip).  Every operand value is carried as two fp16 pieces of its scaled self
  * (v * scale = hi + lo, 22 significant bits) and every product as hi*hi + hi*lo + lo*hi accumulated in fp32
- * by v_mfma_f32_16x16x32_f16: results agree with an fp32 evaluation to ~1e-7 of the input scale (measured
- * against fp64: closer than an fp32 fma chain), at 16x the fp32 matrix rate, which pays for dense 16 x 32
- * blocks of A and 256-row tiles (3.1 staged source rows per result row instead of 5.8).  Arrays:
+ * by v_mfma_f32_16x16x32_f16, at 16x the fp32 matrix rate, which pays for dense 16 x 32 blocks of A and 256-row
+ * tiles (3.2 staged source rows per result row instead of 5.8).
+ * ERROR MODEL.  x is scaled per feature column (x_tab, from sgp_split_prepare_f32), A per row (plan), so the
+ * result is invariant to rescaling a column of x or a row of A, like fp32.  Within 2^16 of its column's bound a
+ * value keeps 22 bits (relative 2^-23); below that the error is absolute, <= 2^-38 x the column's bound.  The
+ * products are exact, sums are fp32.  The kernel is therefore fp32-equivalent exactly where
+ * sgp_split_prepare_f32 sets its flag, and callers launch it under that predicate with an exact kernel behind it.
+ * Arrays:
  *   hdr[n_tiles][64]                         [W : 2 W] rows of each of the W waves, [2 W] staged rows U
- *   rowid[n_tiles][W][rows]                  result row of every slot (16 half + m) of every wave, -1 = empty
+ *   rowid[n_tiles][W][16]                    result row of every slot of every wave, -1 = empty
  *   ucol[n_tiles][max_union]                 source row staged at position s (-1 beyond U)
- *   afr[n_tiles][W][chunks][rows / 8][64][8] fp16   A fragments in lane order (2 * half + piece)
- *   adr[n_tiles][W][chunks][2][64]           per-lane byte address of the transpose reads
- * with W = sgp_spmm_split_waves(), rows = sgp_spmm_split_rows_per_wave() (16 waves x 16 rows by default; 8 x 32 and
- * 12 x 16 are build parameters), the k-slots of a chunk in any order (the planner picks one that keeps the rows a
- * transpose read fetches together on different LDS banks),
- * chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0.  X / X_halo /
- * n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows a node partition received).  x_scale / w_scale: powers of two with |x| * x_scale < 65504 (the caller's bound on |x|) and
- * |a| * w_scale < 65504 (the plan's).  t_chunk = time steps per workgroup (0 = chosen here). */
+ *   afr[n_tiles][W][chunks][2][64][8] fp16   A fragments in lane order (piece 0 | 1) of a[i, :] * 2^e_i
+ *   adr[n_tiles][W][chunks][64]              per-lane byte addresses of the two transpose reads, a0 | a1 << 16
+ *   rinv[n_tiles][W][16]                     2^-e_i of every slot's row (0 for empty slots)
+ * with W = sgp_spmm_split_waves() waves of sgp_spmm_split_rows_per_wave() = 16 rows, the k-slots of a chunk in any
+ * order (the planner picks one that keeps the rows a transpose read fetches together on different LDS banks),
+ * chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0, feat <=
+ * sgp_spmm_split_max_feat().  X / X_halo / n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows
+ * a node partition received).  x_tab: device [2][feat], scale then inverse, |x[:, c]| * x_tab[c] < 65504.
+ * accumulate != 0: Y += A X (the later passes of an operator whose rows were cut into column segments).
+ * t_chunk = time steps per workgroup (0 = chosen here). */
 int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
-                       const int32_t* adr, int32_t n_tiles,
+                       const int32_t* adr, const float* rinv, int32_t n_tiles,
                        const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                        const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                       float x_scale, float w_scale, int32_t t_chunk, sgp_stream_t stream);
+                       const float* x_tab, int32_t accumulate, int32_t t_chunk, sgp_stream_t stream);
 int32_t sgp_spmm_split_chunks(void);
 int32_t sgp_spmm_split_max_union(void);
 int32_t sgp_spmm_split_waves(void);
 int32_t sgp_spmm_split_rows_per_wave(void);
+int32_t sgp_spmm_split_max_feat(void);
 
 /* Column-blocked hop for graphs without locality (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/colblock.py).  The columns are cut into n_blocks blocks of consecutive columns whose source

@@ -29,6 +29,8 @@ struct Src {                      // where column c of step b lives
     const float* x;  long long xrs, xbs;
     const float* xh; long long xhrs, xhbs;
     int n_own;
+    const int* pred; int pred_want;   // launch predicate (common.h)
+    __device__ __forceinline__ bool skip() const { return pred != nullptr && pred[0] != pred_want; }
     __device__ __forceinline__ const float* row(int b, int c) const {
         return (c < n_own) ? x + (long long)b * xbs + (long long)c * xrs
                            : xh + (long long)b * xhbs + (long long)(c - n_own) * xhrs;
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(
     constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows) return;
+    if (row >= n_rows || src.skip()) return;
     const int b0 = blockIdx.y * TB;
     const int f0 = blockIdx.z * (4 * LPR) + (lane % LPR) * 4;
     const int g = lane / LPR;
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void spmm_csr_scalar(
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int b = blockIdx.y;
-    if (row >= n_rows) return;
+    if (row >= n_rows || src.skip()) return;
     const int e0 = rowptr[row], e1 = rowptr[row + 1];
     for (int f = lane; f < feat; f += kWave) {
         float acc = 0.f;
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(NTHR) void spmm_tiled(TiledArgs a) {
     constexpr int NEG = NTHR / 16;                // edge groups per workgroup
 
     // XCD-aware decode: consecutive ids on one XCD = consecutive tiles of one time chunk
+    if (a.src.skip()) return;
     const int nwg = a.n_tiles * a.n_tchunks;
     const int orig = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
@@ -433,12 +436,13 @@ int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
                      float* Y, int64_t yrs, int64_t ybs,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                      sgp_stream_t stream) {
+    const sgp::Predicate pr = sgp::take_predicate();
     SGP_REQUIRE(rowptr && col && val && X && Y, "sgp_spmm_csr_f32: null pointer");
     SGP_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && feat >= 0, "sgp_spmm_csr_f32: negative size");
     SGP_REQUIRE(Xh != nullptr || n_own >= n_cols, "sgp_spmm_csr_f32: n_own < n_cols needs X_halo");
     if (n_rows == 0 || batch == 0 || feat == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    Src src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
+    Src src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff, pr.flag, pr.want};
     const bool vec = feat % 4 == 0 && xrs % 4 == 0 && xbs % 4 == 0 && yrs % 4 == 0 && ybs % 4 == 0 &&
                      sgp::aligned16(X) && sgp::aligned16(Y) &&
                      (!Xh || (xhrs % 4 == 0 && xhbs % 4 == 0 && sgp::aligned16(Xh)));
@@ -472,6 +476,7 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
                        float* Y, int64_t yrs, int64_t ybs,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                        sgp_stream_t stream) {
+    const sgp::Predicate pr = sgp::take_predicate();
     SGP_REQUIRE(trow && uptr && ucol && erow && ecol && eval && X && Y, "sgp_spmm_tiled_f32: null pointer");
     SGP_REQUIRE(tile_rows > 0 && n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 &&
                 max_row_edges >= 0 && max_row_edges % 16 == 0, "sgp_spmm_tiled_f32: bad size");
@@ -497,7 +502,7 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
     TiledArgs a;
     a.trow = trow; a.uptr = uptr; a.ucol = ucol; a.erow = erow; a.ecol = ecol; a.eval = eval;
     a.tile_rows = tile_rows; a.n_tiles = n_tiles;
-    a.src = Src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
+    a.src = Src{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff, pr.flag, pr.want};
     a.Y = Y; a.yrs = yrs; a.ybs = ybs;
     a.n_rows = n_rows; a.batch = batch; a.feat = feat;
     // enough workgroups to balance 256 CUs, long enough chunks to amortise the per-tile setup

@@ -52,11 +52,13 @@ struct CbArgs {
     int nb, batch;
     unsigned* pace;                           // arrival counter of the per-step rendezvous, or null
     unsigned n_arrive;                        // workgroups of the launch
+    const int* pred; int pred_want;           // launch predicate (common.h)
 };
 
 template <bool HALO>
 __global__ __launch_bounds__(kWaves * 64) void spmm_colblock(CbArgs a) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    if (a.pred != nullptr && a.pred[0] != a.pred_want) return;
     const int wg = blockIdx.x;
     const int f_base = blockIdx.y * 64;
     const int tid = threadIdx.x;
@@ -153,6 +155,7 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
                           float* Y, int64_t yrs, int64_t ybs,
                           int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                           sgp_stream_t stream) {
+    const sgp::Predicate pr = sgp::take_predicate();
     SGP_REQUIRE(plan && segptr && wg_row0 && X && Y, "sgp_spmm_colblock_f32: null pointer");
     SGP_REQUIRE(n_wg >= 0 && n_blocks >= 0 && n_rows >= 0 && n_cols >= 0 && batch >= 0 && feat >= 0,
                 "sgp_spmm_colblock_f32: bad size");
@@ -171,6 +174,7 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
     a.x = X; a.xrs = xrs; a.xbs = xbs; a.y = Y; a.yrs = yrs; a.ybs = ybs;
     a.xh = X_halo; a.xhrs = xhrs; a.xhbs = xhbs; a.n_own = X_halo ? n_own : 0x7fffffff;
     a.nb = n_blocks; a.batch = batch;
+    a.pred = pr.flag; a.pred_want = pr.want;
     hipStream_t s = (hipStream_t)stream;
     // per-step rendezvous only when all workgroups are resident at once (one per CU: 128 KB of LDS each)
     a.pace = nullptr; a.n_arrive = (unsigned)n_wg * (unsigned)(feat / 64);

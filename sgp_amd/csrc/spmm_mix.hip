@@ -36,6 +36,8 @@ struct Src2 {
     const float* x;  long long xrs, xbs;
     const float* xh; long long xhrs, xhbs;
     int n_own;
+    const int* pred; int pred_want;        // launch predicate (common.h)
+    __device__ __forceinline__ bool skip() const { return pred != nullptr && pred[0] != pred_want; }
 };
 
 struct MixArgs {
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(NW * 64) void spmm_mix(MixArgs a) {
     constexpr int WH = R::WH, NF = R::NF, SHX = R::SHX;
     constexpr int RPP = NW * 4;
 
+    if (a.src.skip()) return;
     const int nwg = a.n_tiles * a.n_tchunks;
     const int orig = blockIdx.x;
     const int qq = nwg >> 3, rr = nwg & 7, x8 = orig & 7;
@@ -640,6 +643,7 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
                      float* Y, int64_t yrs, int64_t ybs,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
                      sgp_stream_t stream) {
+    const sgp::Predicate pr = sgp::take_predicate();
     SGP_REQUIRE(uptr && ucol && usplit && gptr && gsup && gidx && gw && rowmap && dptr && didx && dw && X && Y,
                 "sgp_spmm_mix_f32: null pointer");
     SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_dense >= 0,
@@ -663,7 +667,7 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
     a.uptr = uptr; a.ucol = ucol; a.usplit = usplit; a.gptr = gptr; a.gsup = gsup; a.gidx = gidx; a.gw = gw;
     a.rowmap = rowmap; a.dptr = dptr; a.didx = didx; a.dw = dw;
     a.n_tiles = n_tiles;
-    a.src = Src2{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff};
+    a.src = Src2{X, xrs, xbs, Xh ? Xh : X, xhrs, xhbs, Xh ? n_own : 0x7fffffff, pr.flag, pr.want};
     a.Y = Y; a.yrs = yrs; a.ybs = ybs;
     a.n_rows = n_rows; a.batch = batch; a.feat = feat;
     const int nft = feat / 64;

@@ -285,7 +285,7 @@ class ShiftOperator:
             return t.is_cuda and t.stride(1) % 4 == 0 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and \
                 t.shape[1] * max(t.stride(1), 1) < 2 ** 29
         return (tune.get("hop", "split") == "split" and ok(x) and ok(y) and (halo is None or ok(halo))
-                and x.shape[2] % 16 == 0
+                and self._split_shape_ok(x)
                 and self.nnz() >= 8 * self.num_nodes and self.num_nodes >= 2048
                 and self.split_plan(x.device) is not None)
 
@@ -303,9 +303,10 @@ class ShiftOperator:
     def propagate(self, x, y, force=None, halo=None, x_bound=None):
         """y[b] = A [x[b]; halo[b]] for strided [B, N, F] CUDA views (no allocation).
         ``halo[B, num_cols - num_nodes, F]`` (any strides) supplies the columns past the
-        owned rows for the local block of a node partition.  ``x_bound`` >= max |x| lets the split-fp16
-        hop pick its scale without measuring (the encoder knows it: bounded activations, row-stochastic
-        operators); None = measured by one reduction pass when that kernel is chosen."""
+        owned rows for the local block of a node partition.  ``x_bound``: what the caller knows about max |x| -- a
+        float (bounded activations), the ``hip.ColumnBound`` the previous hop left in ``self.next_bound``, or None
+        (measured by one pass when the split-fp16 hop is a candidate); it sets that kernel's per-column scales and,
+        with sampled statistics of x, the device-side choice between it and the exact kernel."""
         from . import hip
         if (halo is None) != (self.num_cols == self.num_nodes):
             raise ValueError("halo rows are required exactly when num_cols > num_nodes")
@@ -328,31 +329,80 @@ class ShiftOperator:
             not (halo is not None and halo.shape[1] * max(halo.stride(1), 1) >= 2 ** 30)
         if not fits32 and force in (None, "csr"):
             plan = None
-        # 1. split-fp16 hop: first choice on one GPU where the plan exists; results agree with the
-        # exact-fp32 kernels to ~1e-7 of the operand scale.  SGP_TUNE=hop=exact keeps the fp32 matrix-core kernels.
-        if force == "split" or (force is None and self.split_eligible(x, y, halo)):
-            splan = self.split_plan(x.device) if x.shape[2] % 16 == 0 else None
+        # 1. split-fp16 hop: first choice where the plan exists -- UNDER A DEVICE-SIDE PREDICATE: the
+        # operand's profile (per-column bounds + sampled statistics, hip.split_profile) decides on the device
+        # whether the split kernel meets fp32's accuracy on this operand (flag 1) or the exact kernel enqueued
+        # right behind it must run (flag 0); no host round trip.  SGP_TUNE=hop=exact keeps the exact kernels only,
+        # force="split" runs the split kernel unconditionally (tests, probes).
+        self.next_bound = None
+        self.last_split_flag = None
+        pending = None
+        if isinstance(x_bound, (int, float)):
+            if x_bound == 0:
+                x_bound = None                          # nothing known: measured
+            elif not (0 < x_bound < float("inf")):
+                if force == "split":
+                    raise ValueError("the split-fp16 hop needs a finite bound on |x|")
+                force = force or "exact"                # a non-finite bound: exact kernels
+        if force == "exact":
+            force = None
+        elif force == "split" or (force is None and self.split_eligible(x, y, halo)):
+            splan = self.split_plan(x.device) if self._split_shape_ok(x) else None
             if splan is not None:
-                if x_bound is None:
-                    x_bound = hip.abs_max(x) if halo is None else max(hip.abs_max(x), hip.abs_max(halo))
-                if x_bound == 0.0:
-                    x_bound = 1.0
-                if x_bound == x_bound and x_bound != float("inf"):
+                if force == "split":
+                    prof = hip.spmm_split(splan, x, y, hip.split_profile(x, halo, x_bound, self.norm_inf(), guard=False),
+                                          halo=halo, n_own=self.num_nodes)
                     self.last_kernel = "spmm_split"
-                    hip.spmm_split(splan, x, y, x_bound, halo=halo, n_own=self.num_nodes)
+                    self.next_bound = prof.bound_out
                     return y
-            if force == "split":
+                prof = hip.split_profile(x, halo, x_bound, self.norm_inf(), guard=tune.get("split_guard", 1, int) != 0)
+                hip.spmm_split(splan, x, y, prof, halo=halo, n_own=self.num_nodes, predicated=True)
+                self.next_bound = prof.bound_out
+                pending = prof.flag
+            elif force == "split":
                 raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")
             plan = self.tile_plan(x.shape[2], x.device, tall=True) if fits32 else None
+        try:
+            name = self._propagate_exact(x, y, force, halo, plan, fits32, pending)
+        finally:
+            if pending is not None:
+                hip.launch_predicate(None, 0)          # (consumed by the launch; cleared here if the dispatch raised)
+        if pending is not None:
+            self.last_kernel, self.last_exact_kernel, self.last_split_flag = "spmm_split", name, pending
+        else:
+            self.last_kernel = name
+        return y
+
+    def _split_shape_ok(self, x):
+        from . import hip
+        return x.shape[2] % 16 == 0 and x.shape[2] <= hip.load().sgp_spmm_split_max_feat()
+
+    def resolved_kernel(self):
+        """Name of the kernel that computed the last hop.  Where the split-fp16 hop ran under its predicate this reads
+        the device flag (one 4-byte copy: a sync -- reporting paths only)."""
+        flag = getattr(self, "last_split_flag", None)
+        if flag is None:
+            return getattr(self, "last_kernel", None)
+        return "spmm_split" if int(flag.item()) == 1 else self.last_exact_kernel
+
+    def _propagate_exact(self, x, y, force, halo, plan, fits32, pending):
+        """The exact-fp32 dispatch; ``pending``: device flag of a split-fp16 launch already enqueued for this hop --
+        the kernel chosen here then runs only where that flag is 0.  Returns the kernel's name."""
+        from . import hip
+
+        def launch(fn, *args):
+            if pending is not None:
+                hip.launch_predicate(pending, 0)
+            fn(*args)
+
         # 2. exact fp32 on the matrix cores: the mixed dense (16x16x4) / sparse (4x4x1) kernel where the planner
         # finds enough shared columns (k-NN-like graphs), else the register-resident row-group kernel
         if force in (None, "mix") and plan is not None and fits32 and \
                 (force == "mix" or tune.get("exact", "mix") == "mix"):
             mplan = self.mix_plan(x.shape[2], x.device, strict=force is None)
             if mplan is not None:
-                self.last_kernel = "spmm_mix"
-                hip.spmm_mix(mplan, x, y, halo, self.num_nodes)
-                return y
+                launch(hip.spmm_mix, mplan, x, y, halo, self.num_nodes)
+                return "spmm_mix"
         if force == "mix":
             raise NotImplementedError("no mixed dense / sparse plan for this graph / feature width")
         if force in ("tiled", "res") and plan is None:
@@ -365,9 +415,8 @@ class ShiftOperator:
         if force == "res" and not use_res:
             raise NotImplementedError("no two-phase row-group stream for this plan")
         if use_res:
-            self.last_kernel = "spmm_res"
-            hip.spmm_res(plan, x, y, halo, self.num_nodes)
-            return y
+            launch(hip.spmm_res, plan, x, y, halo, self.num_nodes)
+            return "spmm_res"
         if plan is not None and plan.reordered:
             if force == "tiled":
                 raise NotImplementedError("a reordered plan serves the row-group kernels only")
@@ -383,20 +432,17 @@ class ShiftOperator:
             ok_halo = halo is None or (halo.stride(1) % 4 == 0 and halo.stride(0) % 4 == 0 and halo.data_ptr() % 16 == 0)
             cplan = self.colblock_plan(x.shape[2], x.device) if ok_halo else None
             if cplan is not None:
-                self.last_kernel = "spmm_colblock"
-                hip.spmm_colblock(cplan, x, y, halo, self.num_nodes)
-                return y
+                launch(hip.spmm_colblock, cplan, x, y, halo, self.num_nodes)
+                return "spmm_colblock"
             if force == "colblock":
                 raise NotImplementedError("no column-blocked plan for this operator / feature width / halo")
         # 4. VALU form of the staged kernel (sparse graphs, tall tiles), else the generic CSR kernel
         if plan is not None:
-            self.last_kernel = "spmm_tiled"
-            hip.spmm_tiled(plan, x, y, halo, self.num_nodes)
-        else:
-            self.last_kernel = "spmm_csr_rows"
-            rowptr, col, val = self.device_csr(x.device)
-            hip.spmm_csr(rowptr, col, val, x, y, halo, self.num_nodes)
-        return y
+            launch(hip.spmm_tiled, plan, x, y, halo, self.num_nodes)
+            return "spmm_tiled"
+        rowptr, col, val = self.device_csr(x.device)
+        launch(hip.spmm_csr, rowptr, col, val, x, y, halo, self.num_nodes)
+        return "spmm_csr_rows"
 
     def index_select(self, dim, index):
         """Rows ``index`` (order kept, repeats allowed) as a new rectangular operator -- the

@@ -109,13 +109,17 @@ SIGNATURES = {
     "sgp_grouped_linear_wgrad_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                     c_i32, c_i32, c_i32, c_i32, c_p]),
     "sgp_abs_max_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p, c_p]),
-    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64,
+    "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64,
                                           c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
-                                          c_i32, c_i32, c_i32, c_i32, c_f32, c_f32, c_i32, c_p]),
+                                          c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p]),
+    "sgp_launch_predicate": (ctypes.c_int, [c_p, c_i32]),
+    "sgp_col_stats_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    "sgp_split_prepare_f32": (ctypes.c_int, [c_p, c_f64, c_f64, c_i32, c_p, c_f32, c_f32, c_i32, c_p, c_p, c_p, c_p]),
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
     "sgp_spmm_split_waves": (c_i32, []),
     "sgp_spmm_split_rows_per_wave": (c_i32, []),
+    "sgp_spmm_split_max_feat": (c_i32, []),
     "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64,
                                              c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
                                              c_i32, c_i32, c_i32, c_i32, c_p]),
@@ -160,7 +164,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.sgp_abi_version() != 1:
+    if lib.sgp_abi_version() != 2:
         raise RuntimeError("libsgp_amd.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -323,12 +327,94 @@ def abs_max(x):
     return float(out.item())
 
 
+class ColumnBound:
+    """Per-column upper bounds of |x| as a DEVICE tensor ``[feat]`` (what ``split_profile`` leaves for the next hop:
+    ``bound * ||A||_inf``); a column whose bound is 0 is identically zero."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+class SplitProfile:
+    """Device-side decision record of one split-fp16 hop: ``tab[2, feat]`` (per-column scale | inverse), ``flag[1]``
+    (1 = the operand meets the kernel's precision contract, 0 = the exact kernels must run), ``bound_out`` (the
+    next hop's ``ColumnBound``)."""
+
+    def __init__(self, tab, flag, bound_out):
+        self.tab, self.flag, self.bound_out = tab, flag, bound_out
+
+
+def launch_predicate(flag, run_if):
+    """The next hop launch of this thread runs only if ``flag[0] == run_if`` on the device (None clears)."""
+    lib = require_gpu()
+    _check(lib.sgp_launch_predicate(None if flag is None else flag.data_ptr(), int(run_if)), "sgp_launch_predicate")
+
+
 @_on_device
-def spmm_split(plan, x, y, x_bound, t_chunk=0, halo=None, n_own=None):
-    """Split-fp16 hop (plan: sgp_amd.splitplan.SplitPlan on the device of ``x``).  ``x_bound`` >= max |x|
-    (the caller's guarantee: reservoir states of tanh / self_norm layers are bounded by 1, a hop multiplies
-    the bound by the operator's infinity norm); the scale puts it at 2^13..2^14 of the fp16 range."""
+def col_stats(x, t_stride=1, stats=None):
+    """Per-column max |x| (float bit patterns) and sum of squares of the steps 0, t_stride, .. of a [B, N, D] view,
+    as a device tensor ``[2, D]``; ``stats`` given = accumulate a second source into it."""
+    lib = require_gpu()
+    xp, xrs, xbs = _view3(x, "x")
+    acc = stats is not None
+    if stats is None:
+        stats = torch.empty(2, x.shape[2], dtype=torch.float32, device=x.device)
+    _check(lib.sgp_col_stats_f32(xp, xrs, xbs, x.shape[1], x.shape[0], x.shape[2], int(t_stride), int(acc),
+                                 stats.data_ptr(), _stream(x)), "sgp_col_stats_f32")
+    return stats
+
+
+SPLIT_SAMPLE_STEPS = 32        # steps the admission statistics of a hop read (all of them when there are fewer)
+
+
+@_on_device
+def split_profile(x, halo=None, bound=None, norm_inf=1.0, guard=True):
+    """Enqueue what the split-fp16 hop needs to know about its operand, all on the device (no host sync):
+    per-column statistics of ``x`` (+ ``halo``), then ``sgp_split_prepare_f32`` -> ``SplitProfile``.
+    ``bound``: None = measured (one pass over every row), a float = the caller's a-priori bound on |x| (tanh /
+    self_norm states: 1), or the ``ColumnBound`` the previous hop left.  With a bound the statistics are read from
+    ~``SPLIT_SAMPLE_STEPS`` evenly spaced steps only.  ``guard=False`` skips the statistics altogether (the caller
+    vouches; needs a bound)."""
     import math
+    lib = require_gpu()
+    B, N, D = x.shape
+    dev = x.device
+    out = torch.empty(3 * D + 4, dtype=torch.float32, device=dev)     # tab[2 D] | bound_out[D] | flag
+    tab, bound_out, flag = out[:2 * D].view(2, D), out[2 * D:3 * D], out[3 * D:3 * D + 1].view(torch.int32)
+    if isinstance(bound, ColumnBound):
+        b_in, b_scalar = bound.tensor, 0.0
+        if b_in.numel() != D or b_in.device != dev:
+            raise ValueError("ColumnBound does not match the operand")
+    elif bound is None:
+        b_in, b_scalar = None, 0.0
+    else:
+        b_in, b_scalar = None, float(bound)
+        if not (b_scalar > 0 and math.isfinite(b_scalar)):
+            raise ValueError("split_profile needs a finite positive bound on |x| (or None: measured)")
+    measured = b_in is None and b_scalar == 0.0
+    stats, n_samples, s_eff, full = None, 1.0, 1.0, 0
+    if guard or measured:
+        t_stride = 1 if measured else max(1, B // SPLIT_SAMPLE_STEPS)
+        ns = -(-B // t_stride)
+        stats = col_stats(x, t_stride)
+        rows = N
+        if halo is not None and halo.shape[1] > 0:
+            col_stats(halo, t_stride, stats)
+            rows += halo.shape[1]
+        n_samples, s_eff, full = float(ns) * rows, B / ns, int(t_stride == 1)
+    _check(lib.sgp_split_prepare_f32(None if stats is None else stats.data_ptr(), n_samples, s_eff, full,
+                                     None if b_in is None else b_in.data_ptr(), b_scalar, float(norm_inf), D,
+                                     tab.data_ptr(), bound_out.data_ptr(), flag.data_ptr(), _stream(x)),
+           "sgp_split_prepare_f32")
+    return SplitProfile(tab, flag, ColumnBound(bound_out))
+
+
+@_on_device
+def spmm_split(plan, x, y, profile, t_chunk=0, halo=None, n_own=None, predicated=False):
+    """Split-fp16 hop (plan: sgp_amd.splitplan.SplitPlan on the device of ``x``; ``profile``: the ``SplitProfile``
+    of this operand, or a float bound on |x| / None for which one is made here without the admission test --
+    callers that force the kernel).  ``predicated``: launch under ``profile.flag == 1`` (the caller enqueues the
+    exact kernel under ``== 0`` behind it)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
     yp, yrs, ybs = _view3(y, "y")
@@ -337,14 +423,18 @@ def spmm_split(plan, x, y, x_bound, t_chunk=0, halo=None, n_own=None):
         n_own = x.shape[1] if n_own is None else n_own
     else:
         hp, hrs, hbs, n_own = None, 0, 0, 0
-    if not (x_bound > 0 and math.isfinite(x_bound)):
-        raise ValueError("spmm_split needs a finite positive bound on |x|")
-    x_scale = 2.0 ** math.floor(math.log2(16384.0 / x_bound))
-    _check(lib.sgp_spmm_split_f32(
-        plan.hdr.data_ptr(), plan.rowid.data_ptr(), plan.ucol.data_ptr(), plan.afr.data_ptr(), plan.adr.data_ptr(),
-        plan.n_tiles,
-        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2],
-        x_scale, plan.w_scale, t_chunk, _stream(x)), "sgp_spmm_split_f32")
+    if not isinstance(profile, SplitProfile):
+        profile = split_profile(x, halo, profile, guard=False)
+    plans = plan if isinstance(plan, (list, tuple)) else [plan]
+    for p in plans:                                   # (several passes: an operator whose long rows were cut into column segments)
+        if predicated:
+            launch_predicate(profile.flag, 1)
+        _check(lib.sgp_spmm_split_f32(
+            p.hdr.data_ptr(), p.rowid.data_ptr(), p.ucol.data_ptr(), p.afr.data_ptr(), p.adr.data_ptr(),
+            p.rinv.data_ptr(), p.n_tiles,
+            xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, p.n_rows, p.n_cols, x.shape[0], x.shape[2],
+            profile.tab.data_ptr(), int(p.accumulate), t_chunk, _stream(x)), "sgp_spmm_split_f32")
+    return profile
 
 
 @_on_device

@@ -89,6 +89,7 @@ def _rank_main(rank, world, port, desc, x, edge_index, edge_weight, out, shard_d
         tc = int(tcs.item())
         L, R = len(enc.reservoir.reservoir_layers), enc.reservoir.hidden_size
         state = torch.zeros(L, n_own, R, dtype=torch.float32, device=dev)
+        state._sgp_unit_bounded = True                          # starts at zero (SGPEncoder._state_bound)
         buf = torch.empty(tc, n_own, d_out, dtype=torch.float32, device=dev)
         shards = []
         for t0 in range(0, T, tc):
@@ -111,7 +112,7 @@ def _rank_main(rank, world, port, desc, x, edge_index, edge_weight, out, shard_d
             blk = spatial.blocks[0]
             q.put(dict(bounds=[int(b) for b in bounds], t_chunk=tc, backend=backend, world=world,
                        reordered=spatial.node_order is not None,
-                       kernel=getattr(blk.op, "last_kernel", None), halo_rows=int(blk.n_halo)))
+                       kernel=blk.op.resolved_kernel(), halo_rows=int(blk.n_halo)))
         if shard_dir is not None:
             q.put(dict(rank=rank, shards=shards))
     finally:

@@ -144,11 +144,20 @@ class SGPEncoder(nn.Module):
         hop_us = (self.sgp_encoder.num_blocks() - 1) * N * L * R * 8 / 4e6   # bytes of the hop blocks at ~4 TB/s
         return self.overlap_chunks if hop_us >= 0.25 * chain_us else 1
 
-    def _state_bound(self):
-        """Upper bound of |reservoir state| where the activation gives one: a leaky average of values in
-        [-1, 1] started from 0 stays in [-1, 1] (tanh; self_norm rows have unit 2-norm).  relu / identity
-        states are unbounded: None = the hop measures its operand."""
-        return 1.0 if self.reservoir.mode in ("tanh", "self_norm") else None
+    def _state_bound(self, state=None):
+        """Upper bound of |reservoir state| where one holds: a leaky average ``(1 - a) h + a act(.)`` of values in
+        [-1, 1] stays in [-1, 1] (tanh; self_norm rows have unit 2-norm) PROVIDED every layer's leaking rate lies in
+        [0, 1] (the reference accepts any float, reservoir.py:109-123) and the recurrence starts inside the
+        interval -- from zero, or from a state this encoder produced itself under the same premises (marked
+        ``_sgp_unit_bounded`` by ``encode_device``).  Everything else -- relu / identity, a leaking rate outside
+        [0, 1], a state handed in by the caller -- returns None: the hop measures its operand."""
+        if self.reservoir.mode not in ("tanh", "self_norm"):
+            return None
+        if not all(0.0 <= float(l.alpha) <= 1.0 for l in self.reservoir.reservoir_layers):
+            return None
+        if state is not None and not getattr(state, "_sgp_unit_bounded", False):
+            return None
+        return 1.0
 
     def encode_device(self, x, ops, out=None, state=None, timeline=None):
         """x[T, N, F] CUDA float32 -> out[T, N, D_out] on the same device.  ``state`` [L, N, R]:
@@ -159,17 +168,21 @@ class SGPEncoder(nn.Module):
         if out is None:
             out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
         chunks = self._overlap_pieces(T, N)
+        x_bound = self._state_bound(state)
         # global_attr: the column sums of the states come from the reservoir kernel where it has them
         # in registers (fused stacked kernel); the other kernels keep the fused mean + broadcast pass
         want_sums = self.sgp_encoder.global_attr and self.reservoir.produces_col_sums(x)
         if chunks <= 1:
             sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
             self.reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
-            self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums, x_bound=self._state_bound())
+            self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums, x_bound=x_bound)
+            if state is not None and x_bound is not None:
+                state._sgp_unit_bounded = True                  # (carried on: encode_streamed, the time pieces below)
             return out
         if state is None:
             state = torch.zeros(len(self.reservoir.reservoir_layers), N, self.reservoir.hidden_size,
                                 dtype=torch.float32, device=x.device)
+            state._sgp_unit_bounded = True
         main = torch.cuda.current_stream(x.device)
         key = str(x.device)
         if key not in self._side_streams:
@@ -185,7 +198,7 @@ class SGPEncoder(nn.Module):
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline, col_sums=sums,
-                                             x_bound=self._state_bound())
+                                             x_bound=x_bound)
                 if sums is not None:
                     sums.record_stream(side)
         main.wait_stream(side)
@@ -241,6 +254,7 @@ class SGPEncoder(nn.Module):
             return out
         out_pinned = out.is_pinned()
         state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
+        state._sgp_unit_bounded = True                          # starts at zero (see _state_bound)
         nbuf = 2 if len(starts) > 1 else 1
         xin = [torch.empty(tc, N, F, dtype=torch.float32, device=dev) for _ in range(nbuf)]
         buf = [torch.empty(tc, N, D, dtype=torch.float32, device=dev) for _ in range(nbuf)]
@@ -349,6 +363,7 @@ class SGPEncoder(nn.Module):
         per_step = N * (F + D) * 4
         ts = max(1, min(int(shard_steps), T, self._budget() // max(1, 2 * per_step)))
         state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
+        state._sgp_unit_bounded = True                          # starts at zero (see _state_bound)
         buf = torch.empty(ts, N, D, dtype=torch.float32, device=dev)
         pin = torch.empty(ts, N, D, dtype=torch.float32, pin_memory=True)
         paths = []

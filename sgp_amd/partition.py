@@ -375,8 +375,13 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     ``x[T, n_own, F]``, ``out[T, n_own, P * D_h]`` on the GPU."""
     T = x.shape[0]
     d_h = reservoir.output_size
-    # bounded activations bound the states on every rank alike (sgp_encoder.SGPEncoder._state_bound)
-    bound = 1.0 if getattr(reservoir, "mode", None) in ("tanh", "self_norm") and x.is_cuda else None
+    # bounded activations bound the states on every rank alike -- under the premises of
+    # sgp_encoder.SGPEncoder._state_bound: leaking rates in [0, 1], a recurrence that starts inside [-1, 1]
+    bound = None
+    if x.is_cuda and getattr(reservoir, "mode", None) in ("tanh", "self_norm") and \
+            all(0.0 <= float(l.alpha) <= 1.0 for l in reservoir.reservoir_layers) and \
+            (state is None or getattr(state, "_sgp_unit_bounded", False)):
+        bound = 1.0
     pieces = spatial.n_chunks if pieces is None else pieces
     pieces = max(1, min(int(pieces), T // 8)) if x.is_cuda else 1
     want_sums = spatial.global_attr and x.is_cuda and reservoir.produces_col_sums(x)
@@ -387,6 +392,8 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     if state is None:
         state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
                             dtype=torch.float32, device=x.device)
+    if bound is not None:
+        state._sgp_unit_bounded = True
     main = torch.cuda.current_stream(x.device)
     if spatial._res_stream is None:
         spatial._res_stream = torch.cuda.Stream(device=x.device)

@@ -76,8 +76,9 @@ def propagate_into(out, feat, ops, k, timeline=None, x_bound=None):
     temporaries: every hop reads one slot and writes the next.  ``timeline``: a list that
     receives one (start, end) pair of ``hip.Event`` per hop launch, recorded on the stream the
     hop runs on (bench.py's roofline timing).  ``x_bound`` >= max |slot 0| where the caller knows it
-    (bounded reservoir activations); the split-fp16 hop scales its operand by it, a hop multiplies
-    the bound by the operator's infinity norm, and an unknown bound is measured once per direction."""
+    (bounded reservoir activations); the split-fp16 hop derives its per-column scales from it, every hop hands the
+    next one per-column bounds (``op.next_bound`` = bound x the operator's infinity norm, on the device), and an
+    unknown bound is measured by the first hop of a direction."""
     for d, op in enumerate(ops):
         src = out[:, :, 0:feat]
         bound = x_bound
@@ -88,12 +89,8 @@ def propagate_into(out, feat, ops, k, timeline=None, x_bound=None):
                 from . import hip
                 a, b = hip.Event(), hip.Event()
                 a.record()
-            if bound is None and k > 0 and op.split_eligible(src, dst):
-                from . import hip
-                bound = hip.abs_max(src)
             op.propagate(src, dst, x_bound=bound)
-            if bound is not None:
-                bound = bound * max(op.norm_inf(), 1e-30) * (1 + 1e-6)
+            bound = getattr(op, "next_bound", None)
             if timeline is not None:
                 b.record()
                 timeline.append((a, b))

@@ -9,12 +9,16 @@ columns, waves to TILES of at most ``waves`` waves whose rows touch at most ``ma
 * ``rowid[tile, w, slot]``  result row of slot ``16 half + m`` of wave w, -1 = empty slot (rows are dealt in the
                            given numbering or, for numberings without locality, in ``order``)
 * ``ucol[tile, s]``        column (= source row) staged at position s, -1 beyond U
-* ``afr[tile, w, c, q]``   A fragments of ``v_mfma_f32_16x16x32_f16`` in lane order, q = 2 * half + piece:
-                           lane ``m + 16 g``, element e = piece of ``a[row slot 16 half + m, column k = 8 g + e of
-                           chunk c] * w_scale`` (piece 0: the value truncated to fp16, piece 1: the rounded rest)
-* ``adr[tile, w, c, j]``   per-lane byte address (inside a staged unit: a group of 8 staged rows is 512 bytes, the hi
-                           pieces of row r at ``32 r``, the lo pieces at ``256 + 32 r``) of the two transpose reads that fetch a chunk's B operand: lane
-                           ``i + 16 g`` points at the staged row of column ``k = 8 g + 4 j + i / 4``, bytes ``8 (i % 4)``
+* ``afr[tile, w, c, q]``   A fragments of ``v_mfma_f32_16x16x32_f16`` in lane order, q = piece:
+                           lane ``m + 16 g``, element e = piece of ``a[row slot m, column k = 8 g + e of
+                           chunk c] * 2^e_row`` (piece 0: the value truncated to fp16, piece 1: the rounded rest);
+                           every row has its own power-of-two scale (its largest entry lands in [2^13, 2^14]), so the
+                           kernel is as indifferent to the scale of a row of A as fp32 is
+* ``rinv[tile, w, slot]``  ``2^-e_row`` of the slot's row (0 for empty slots): the kernel multiplies the result by it
+* ``adr[tile, w, c]``      per-lane byte addresses (inside a staged unit: a group of 8 staged rows is 512 bytes, the hi
+                           pieces of row r at ``32 r``, the lo pieces at ``256 + 32 r``) of the two transpose reads that
+                           fetch a chunk's B operand, packed ``a0 | a1 << 16``: read j of lane ``i + 16 g`` points at the
+                           staged row of column ``k = 8 g + 4 j + i / 4``, bytes ``8 (i % 4)``
 
 Columns a wave does not use up to ``32 * chunks`` are padded with weight 0 and the address of staged row 0
 (finite data, so 0 * x stays 0).  Duplicate entries of a row are summed before the split.
@@ -24,15 +28,18 @@ import torch
 
 
 class SplitPlan:
-    def __init__(self, hdr, rowid, ucol, afr, adr, n_tiles, n_rows, n_cols, w_scale, norm_inf, stats):
-        self.hdr, self.rowid, self.ucol, self.afr, self.adr = hdr, rowid, ucol, afr, adr
+    def __init__(self, hdr, rowid, ucol, afr, adr, rinv, n_tiles, n_rows, n_cols, norm_inf, stats):
+        self.hdr, self.rowid, self.ucol, self.afr, self.adr, self.rinv = hdr, rowid, ucol, afr, adr, rinv
         self.n_tiles, self.n_rows, self.n_cols = n_tiles, n_rows, n_cols
-        self.w_scale, self.norm_inf, self.stats = w_scale, norm_inf, stats
+        self.norm_inf, self.stats = norm_inf, stats
+        self.accumulate = False          # later passes of an operator whose long rows were cut into column segments
 
     def to(self, device):
-        return SplitPlan(self.hdr.to(device), self.rowid.to(device), self.ucol.to(device), self.afr.to(device),
-                         self.adr.to(device), self.n_tiles, self.n_rows, self.n_cols, self.w_scale, self.norm_inf,
-                         self.stats)
+        p = SplitPlan(self.hdr.to(device), self.rowid.to(device), self.ucol.to(device), self.afr.to(device),
+                      self.adr.to(device), self.rinv.to(device), self.n_tiles, self.n_rows, self.n_cols, self.norm_inf,
+                      self.stats)
+        p.accumulate = self.accumulate
+        return p
 
 
 def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=32, order=None):
@@ -135,7 +142,7 @@ def _bank_aware_slots(w_of_key, pos_of_key, stage, n_chunks_total, chunks):
     return chunk * 32 + slot
 
 
-def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_union=768, order=None, rows_per_wave=32):
+def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None, rows_per_wave=16):
     """``order``: optional permutation of the rows (a locality order of the graph): rows are dealt to waves in
     that sequence while the plan keeps addressing rows and columns by their ORIGINAL ids, so no tensor is
     ever permuted."""
@@ -144,8 +151,7 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     val = np.asarray(val, dtype=np.float32)
     if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
         return None
-    assert rows_per_wave in (16, 32)
-    nh = rows_per_wave // 16                                            # 16-row halves per wave
+    assert rows_per_wave == 16
     deal = deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wave=rows_per_wave, order=order)
     if deal is None:
         return None
@@ -196,21 +202,29 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
     sl = srow[:, :, :, :, lane_i >> 2]
     a = (sl >> 3) * 512 + (sl & 7) * 32 + 8 * (lane_i & 3)               # [wave, chunk, g, j, i]: hi piece of the row
     a = a.transpose(0, 1, 3, 2, 4).reshape(n_waves, chunks, 2, 64)       # lane = 16 g + i
-    adr = np.zeros((n_tiles, waves, chunks, 2, 64), dtype=np.int32)
-    adr[tile_of_wave, w_in_tile] = a
+    assert int(a.max()) < 65536
+    adr = np.zeros((n_tiles, waves, chunks, 64), dtype=np.int32)
+    adr[tile_of_wave, w_in_tile] = (a[:, :, 0] | (a[:, :, 1] << 16)).astype(np.int32)
 
-    # A fragments: sum duplicates in fp32, scale, split
+    # A fragments: sum duplicates in fp32, scale every row by its own power of two, split
     pos = pos_of_key[winv]
     slot = slot_of_row[row_of_edge]
     k = pos % 32
-    dense = np.zeros((n_waves, chunks, nh, 64, 8), dtype=np.float32)     # [wave, chunk, half, lane, e]
-    np.add.at(dense, (e_wave, pos // 32, slot // 16, (slot % 16) + 16 * (k // 8), k % 8), val)
-    amax = float(np.abs(dense).max())                                    # after the duplicates were summed
-    w_scale = float(2.0 ** np.floor(np.log2(16384.0 / amax))) if amax > 0 else 1.0
-    hi, lo = split_fp16(dense * np.float32(w_scale))
-    afr = np.zeros((n_tiles, waves, chunks, 2 * nh, 64, 8), dtype=np.float16)
-    afr[tile_of_wave, w_in_tile, :, 0::2] = hi
-    afr[tile_of_wave, w_in_tile, :, 1::2] = lo
+    dense = np.zeros((n_waves, chunks, 64, 8), dtype=np.float32)         # [wave, chunk, lane, e], lane = slot + 16 (k / 8)
+    np.add.at(dense, (e_wave, pos // 32, slot + 16 * (k // 8), k % 8), val)
+    rmax = np.abs(dense).reshape(n_waves, chunks, 4, 16, 8).max(axis=(1, 2, 4))          # [wave, slot], after the duplicates were summed
+    with np.errstate(divide="ignore"):
+        e_row = np.where(rmax > 0, np.floor(np.log2(16384.0 / np.maximum(rmax, 1e-300))), 0.0)
+    e_row = np.clip(e_row, -126, 126)
+    rscale = np.exp2(e_row).astype(np.float32)                           # [wave, slot]
+    lane_scale = np.tile(rscale, (1, 4))                                 # lane = slot + 16 g
+    hi, lo = split_fp16(dense * lane_scale[:, None, :, None])
+    afr = np.zeros((n_tiles, waves, chunks, 2, 64, 8), dtype=np.float16)
+    afr[tile_of_wave, w_in_tile, :, 0] = hi
+    afr[tile_of_wave, w_in_tile, :, 1] = lo
+    rinv = np.zeros((n_tiles, waves, 16), dtype=np.float32)
+    filled = np.arange(16)[None, :] < rows[:, None]
+    rinv[tile_of_wave, w_in_tile] = np.where(filled, np.exp2(-e_row), 0.0).astype(np.float32)
 
     hdr = np.zeros((n_tiles, 64), dtype=np.int32)
     hdr[tile_of_wave, waves + w_in_tile] = rows
@@ -224,13 +238,13 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=8, chunks=9, max_un
                  rows_per_tile=float(n_rows / n_tiles), staged_per_row=float(union.sum() / n_rows),
                  chunk_fill=float(wkey.size / (n_waves * chunks * 32)), max_union=int(union.max()))
     return SplitPlan(torch.from_numpy(hdr), torch.from_numpy(rowid), torch.from_numpy(ucol), torch.from_numpy(afr), torch.from_numpy(adr),
-                     n_tiles, n_rows, n_cols, w_scale, float(rowsum.max()), stats)
+                     torch.from_numpy(rinv), n_tiles, n_rows, n_cols, float(rowsum.max()), stats)
 
 
 def plan_matrix(plan, n_rows, n_cols):
     """Dense matrix a plan encodes (hi + lo pieces, unscaled): test helper."""
     hdr, ucol, rowid = plan.hdr.numpy(), plan.ucol.numpy(), plan.rowid.numpy()
-    afr, adr = plan.afr.numpy().astype(np.float64), plan.adr.numpy()
+    afr, adr, rinv = plan.afr.numpy().astype(np.float64), plan.adr.numpy(), plan.rinv.numpy().astype(np.float64)
     waves, chunks = afr.shape[1], afr.shape[2]
     out = np.zeros((n_rows, n_cols))
     for t in range(plan.n_tiles):
@@ -244,10 +258,9 @@ def plan_matrix(plan, n_rows, n_cols):
                         kk = 8 * g + e
                         j, i4 = (kk % 8) // 4, kk % 4
                         src_lane = 16 * g + 4 * i4                      # any lane with i / 4 == i4
-                        a_ = int(adr[t, w, c, j, src_lane])
+                        a_ = (int(adr[t, w, c, src_lane]) >> (16 * j)) & 0xFFFF
                         s = (a_ // 512) * 8 + (a_ % 512) // 32
-                        for half in range(afr.shape[3] // 2):
-                            v = afr[t, w, c, 2 * half, lane, e] + afr[t, w, c, 2 * half + 1, lane, e]
-                            if v != 0.0:
-                                out[int(rowid[t, w, 16 * half + m]), int(ucol[t, s])] += v / plan.w_scale
+                        v = afr[t, w, c, 0, lane, e] + afr[t, w, c, 1, lane, e]
+                        if v != 0.0:
+                            out[int(rowid[t, w, m]), int(ucol[t, s])] += v * rinv[t, w, m]
     return out

@@ -35,7 +35,7 @@ def test_binding_covers_header(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.sgp_abi_version() == 1
+    assert lib.sgp_abi_version() == 2
     assert lib.sgp_build_arch() == b"gfx950"
 
 
@@ -144,8 +144,9 @@ if not torch.cuda.is_available():
             n_plans += 1
         sp = op.split_plan(cpu)
         if sp is not None and feat %% 16 == 0:
-            rc = lib.sgp_spmm_split_f32(P(sp.hdr), P(sp.rowid), P(sp.ucol), P(sp.afr), P(sp.adr), sp.n_tiles, P(x), feat, n * feat,
-                                        None, 0, 0, 0, P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, 1.0, sp.w_scale, 0, None)
+            tab = torch.ones(2, feat)
+            rc = lib.sgp_spmm_split_f32(P(sp.hdr), P(sp.rowid), P(sp.ucol), P(sp.afr), P(sp.adr), P(sp.rinv), sp.n_tiles, P(x), feat, n * feat,
+                                        None, 0, 0, 0, P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, P(tab), 0, 0, None)
             assert isinstance(rc, int) and rc != 0
             n_plans += 1
     # reservoir layer: every dispatch branch of the launch logic (split-J, exact deal + tail, even deal, stream)

@@ -7,7 +7,12 @@ import torch
 
 from sgp_amd import graph, splitplan, synthetic
 
-LIM = dict(waves=8, chunks=9, max_union=768)
+LIM = dict(waves=16, chunks=7, max_union=768)
+
+
+def _unpack(adr):
+    """[..., 64] packed a0 | a1 << 16 -> [..., 2, 64] byte addresses of the two transpose reads."""
+    return np.stack([adr & 0xFFFF, (adr >> 16) & 0xFFFF], axis=-2)
 
 
 def _op(ei, ew, n):
@@ -19,10 +24,10 @@ def _plan(op, **kw):
                                       op.num_cols, **{**LIM, **kw})
 
 
-def _check_limits(plan, n_rows, waves=8, chunks=9, max_union=768):
+def _check_limits(plan, n_rows, waves=16, chunks=7, max_union=768):
     hdr = plan.hdr.numpy()
     cnt, union = hdr[:, waves:2 * waves], hdr[:, 2 * waves]
-    assert cnt.max() <= 32 and cnt.min() >= 0 and union.max() <= max_union
+    assert cnt.max() <= 16 and cnt.min() >= 0 and union.max() <= max_union
     assert int(cnt.sum()) == n_rows
     # every row sits in exactly one slot; a wave's slots are filled from 0
     rowid = plan.rowid.numpy()
@@ -34,11 +39,16 @@ def _check_limits(plan, n_rows, waves=8, chunks=9, max_union=768):
         u = int(union[t])
         assert (ucol[t, :u] >= 0).all() and (ucol[t, u:] == -1).all()
         assert len(np.unique(ucol[t, :u])) == u
-    adr = plan.adr.numpy()
+    adr = _unpack(plan.adr.numpy())
     srow = (adr // 512) * 8 + (adr % 512) // 32
     assert (srow < np.maximum(union, 1)[:, None, None, None, None]).all()     # every address is a staged row
     used = cnt > 0
     assert ((adr[used] % 32) // 8 == (np.arange(64) & 3)).all()
+    # every filled slot carries the inverse of a power-of-two row scale, empty slots 0
+    rinv = plan.rinv.numpy()
+    assert ((rinv > 0) == (rowid >= 0)).all()
+    m, _ = np.frexp(rinv[rinv > 0])
+    assert (m == 0.5).all()
 
 
 @pytest.mark.parametrize("n,k", [(700, 20), (500, 100), (300, 7), (1300, 60)])
@@ -76,11 +86,11 @@ def test_duplicates_empty_rows_and_ragged_degrees():
 
 def test_rows_beyond_a_waves_budget_have_no_plan():
     n = 600
-    src = np.concatenate([np.arange(n), np.arange(300)])                      # row 5 touches 300 columns
+    src = np.concatenate([np.arange(n), np.arange(300)])                      # row 5 touches 300 columns (7 chunks hold 224)
     tgt = np.concatenate([np.arange(n), np.full(300, 5)])
     op = _op(torch.from_numpy(np.stack([src, tgt])), None, n)
     assert _plan(op) is None
-    assert _plan(op, chunks=10) is not None
+    assert _plan(op, chunks=10, max_union=1024) is not None
 
 
 def test_small_budgets_cut_waves_and_tiles():
@@ -106,7 +116,7 @@ def test_split_fp16_pieces():
 
 
 def test_locality_order_serves_scrambled_numberings():
-    """Scrambled node labels: dealt in the given numbering a wave's 32 rows share nothing (few rows per wave,
+    """Scrambled node labels: dealt in the given numbering a wave's 16 rows share nothing (few rows per wave,
     many staged rows per result row); dealt in a locality order of the graph the plan is as good as on the
     ordered graph -- and still addresses rows and columns by their original ids."""
     n = 3000
@@ -123,16 +133,26 @@ def test_locality_order_serves_scrambled_numberings():
     assert np.abs(splitplan.plan_matrix(plan, n, n) - dense).max() <= 2.0 ** -21 * dense.max()
 
 
-def test_sixteen_waves_of_sixteen_rows():
-    """The other build shape of the kernel: 16 waves x 16 rows (one 16-row half per wave, 8 chunks)."""
+def test_other_build_shapes_and_row_scales():
+    """Another build shape of the kernel (12 waves, 8 chunks), and rows of very different magnitude: every row is
+    scaled by its own power of two, so a row of weights ~1e-9 beside rows of weights ~1 keeps its 22 bits."""
     ei, ew, _ = synthetic.knn_graph(900, 40, seed=5)
     op = _op(ei, ew, 900)
-    plan = _plan(op, waves=16, chunks=8, rows_per_wave=16)
-    assert plan is not None and plan.rowid.shape[1:] == (16, 16) and plan.afr.shape[1:4] == (16, 8, 2)
+    plan = _plan(op, waves=12, chunks=8)
+    assert plan is not None and plan.rowid.shape[1:] == (12, 16) and plan.afr.shape[1:4] == (12, 8, 2)
     hdr = plan.hdr.numpy()
-    assert hdr[:, 16:32].max() <= 16 and int(hdr[:, 16:32].sum()) == 900 and hdr[:, 32].max() <= 768
+    assert hdr[:, 12:24].max() <= 16 and int(hdr[:, 12:24].sum()) == 900 and hdr[:, 24].max() <= 768
     dense = op.to_dense().numpy().astype(np.float64)
     assert np.abs(splitplan.plan_matrix(plan, 900, 900) - dense).max() <= 2.0 ** -21 * dense.max()
+    rowscale = np.where(np.arange(900) % 3 == 0, 1e-9, np.where(np.arange(900) % 3 == 1, 1.0, 1e7))
+    rows = np.repeat(np.arange(900), np.diff(op.rowptr.numpy()))
+    val = (op.val.numpy().astype(np.float64) * rowscale[rows]).astype(np.float32)
+    plan = splitplan.build_split_plan(op.rowptr.numpy(), op.col.numpy(), val, 900, 900, **LIM)
+    _check_limits(plan, 900)
+    dense = np.zeros((900, 900))
+    np.add.at(dense, (rows, op.col.numpy()), val.astype(np.float64))
+    got = splitplan.plan_matrix(plan, 900, 900)
+    assert (np.abs(got - dense).max(1) <= 2.0 ** -21 * np.abs(dense).max(1)).all()       # row by row
 
 
 def test_k_slots_keep_the_rows_of_a_transpose_read_on_different_banks():
@@ -143,8 +163,8 @@ def test_k_slots_keep_the_rows_of_a_transpose_read_on_different_banks():
     n = 6000
     ei, ew, _ = synthetic.knn_graph(n, 60, seed=3)
     op = _op(ei, ew, n)
-    plan = _plan(op, waves=16, chunks=8, rows_per_wave=16)
-    adr, hdr = plan.adr.numpy(), plan.hdr.numpy()
+    plan = _plan(op, waves=16, chunks=8)
+    adr, hdr = _unpack(plan.adr.numpy()), plan.hdr.numpy()
     a = adr[hdr[:, 16:32] > 0]                                 # [wave, chunk, read, lane]
     s = (a // 512) * 8 + (a % 512) // 32
     cycles = []

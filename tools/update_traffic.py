@@ -1,5 +1,6 @@
 """profiles/traffic.json from the committed rocprofv3 counter summaries: per (workload, kernel) the fabric
-bytes of one hop launch = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 FETCH_SIZE correction,
+bytes of one hop launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB (the counters are in units of 1024 bytes:
+WRITE_SIZE x 1024 is exactly the result slab on the target line) (gfx950 FETCH_SIZE correction,
 MI355X_MICROARCH.md HBM section).  python tools/update_traffic.py r3 target:spmm_mix c3:spmm_mix c2:spmm_tiled:8 ...
 (a third field = the number of time pieces a pass cuts a hop into: the counters are per dispatch, the table
 is per hop over the whole time axis, which is what bench.py divides by its own piece count)"""
@@ -39,11 +40,11 @@ def main():
         t = min(w["T"], w.get("t_chunk", w["T"]))
         alg = bench.hop_bytes(w["N"], t, d_h, int(ei.shape[1]))
         c = {k: v * pieces for k, v in c.items()}
-        b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1000.0
+        b = (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
         table[key] = {"bytes_per_launch": b, "fetch_size_kb_raw": c["FETCH_SIZE"], "write_size_kb": c["WRITE_SIZE"],
                       "algorithmic_bytes": alg, "ratio_to_algorithmic": round(b / alg, 3),
                       "source": f"{summ} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py "
-                                f"--workload {wl}`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB, gfx950 FETCH_SIZE correction "
+                                f"--workload {wl}`; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024, gfx950 FETCH_SIZE correction "
                                 f"of MI355X_MICROARCH.md)"}
         print(key, table[key]["bytes_per_launch"], table[key]["ratio_to_algorithmic"])
     json.dump(table, open(path, "w"), indent=1)

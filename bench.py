@@ -38,6 +38,10 @@ WORKLOADS = {
     # BASELINE.json configs[0] / [3] shapes (real data files are not available; synthetic graphs)
     "c1": dict(N=207, T=34272, F=3, R=64, L=1, K=2, bidir=False, glob=False, graph="traffic"),
     "c4": dict(N=5016, T=8868, F=3, R=16, L=8, K=2, bidir=False, glob=True, graph="knn100"),
+    # the reference's FULL large-scale graphs (adj_knn=None: config/largescale/sgp_pv.yaml / sgp_cer.yaml with
+    # experiments/run_largescale_sgp.py:167-170): every pair above the similarity threshold, ~740 / ~495 entries per row
+    "c4full": dict(N=5016, T=8868, F=3, R=16, L=8, K=2, bidir=False, glob=True, graph="thr740"),
+    "cerfull": dict(N=6435, T=8868, F=3, R=16, L=8, K=2, bidir=False, glob=True, graph="thr495"),
     "c3": dict(N=10000, T=2016, F=64, R=64, L=1, K=4, bidir=False, glob=False, graph="knn100"),
     "c2": dict(N=325, T=52116, F=3, R=128, L=1, K=4, bidir=True, glob=True, graph="traffic"),
     "small": dict(N=4000, T=64, F=64, R=64, L=1, K=2, bidir=True, glob=True, graph="knn100"),
@@ -55,7 +59,9 @@ WORKLOADS = {
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 GRAPH_NAMES = {"knn100": "100-NN geometric graph (Morton order)", "traffic": "traffic-like sparse graph",
                "random100": "100 uniformly random columns per row (no locality)",
-               "random30": "30 uniformly random columns per row (no locality)"}
+               "random30": "30 uniformly random columns per row (no locality)",
+               "thr740": "thresholded Gaussian-kernel graph, ~740 entries per row (PV-US full-graph shape)",
+               "thr495": "thresholded Gaussian-kernel graph, ~495 entries per row (CER-En full-graph shape)"}
 
 
 def profiled_traffic(workload, kernel):
@@ -75,6 +81,8 @@ def profiled_traffic(workload, kernel):
 def build_graph(w):
     if w["graph"] == "knn100":
         ei, ew, _ = synthetic.knn_graph(w["N"], 100, seed=1)
+    elif w["graph"].startswith("thr"):
+        ei, ew, _ = synthetic.threshold_graph(w["N"], int(w["graph"][3:]), seed=1)
     elif w["graph"] in ("random100", "random30"):
         ei, ew = synthetic.random_graph(w["N"], int(w["graph"][6:]), seed=1)
     else:

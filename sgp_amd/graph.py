@@ -248,9 +248,9 @@ class ShiftOperator:
         return self._plans[key]
 
     def split_plan(self, device):
-        """Plan of the split-fp16 hop (``sgp_amd.splitplan``, kernel ``sgp_spmm_split_f32``) or None: every
-        row must fit a wave's column budget (<= 32 * chunks distinct columns) -- graphs with very long rows
-        keep the exact-fp32 kernels."""
+        """Plan of the split-fp16 hop (``sgp_amd.splitplan``, kernel ``sgp_spmm_split_f32``) or None.  Operators with
+        rows longer than a wave's column budget (the reference's full PV-US / CER-En graphs) get a LIST of plans, one
+        per pass over a segment of the columns (``splitplan.build_split_passes``); ``hip.spmm_split`` takes either."""
         key = ("split", str(device))
         if key not in self._plans:
             plan = None
@@ -261,7 +261,7 @@ class ShiftOperator:
                            max_union=lib.sgp_spmm_split_max_union(), rows_per_wave=lib.sgp_spmm_split_rows_per_wave())
                 args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
                 plan = splitplan.build_split_plan(*args, **lim)
-                # numberings without locality (32 consecutive rows share no columns): deal the rows in a
+                # numberings without locality (16 consecutive rows share no columns): deal the rows in a
                 # locality order of the graph itself, as the tile plans do
                 if plan is not None and plan.stats["rows_per_wave"] < 0.75 * lim["rows_per_wave"] and self.num_nodes >= 2048 and \
                         self.num_cols == self.num_nodes:
@@ -273,7 +273,13 @@ class ShiftOperator:
                 if plan is not None and (plan.stats["rows_per_wave"] < 0.375 * lim["rows_per_wave"] or
                                          plan.stats["staged_per_row"] > 8):
                     plan = None
-                if plan is not None:
+                if plan is None and self.max_degree() > 32 * lim["chunks"] and tune.get("split_passes", 1, int) != 0:
+                    # long rows: several passes over column segments, accumulated in place
+                    passes = splitplan.build_split_passes(*args, max_passes=12, **lim)
+                    if passes is not None and passes[0].stats["rows_per_wave"] >= 0.5 * lim["rows_per_wave"] and \
+                            passes[0].stats["staged_per_row"] <= 8:
+                        plan = SplitPasses(p.to(device) for p in passes)
+                elif plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
         return self._plans[key]
@@ -490,6 +496,18 @@ class ShiftOperator:
         if on_cpu:
             y = y.cpu()
         return y.reshape(*lead, self.num_nodes, x.shape[-1])
+
+
+class SplitPasses(list):
+    """Plans of the passes of a long-row operator (``splitplan.build_split_passes``); ``stats`` of the first pass."""
+
+    @property
+    def stats(self):
+        return self[0].stats
+
+    @property
+    def n_tiles(self):
+        return sum(p.n_tiles for p in self)
 
 
 @dataclass

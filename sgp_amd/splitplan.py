@@ -48,8 +48,8 @@ def deal_rows(rowptr, col, n_rows, n_cols, waves, chunks, max_union, rows_per_wa
     cap = 32 * chunks
     wmark = np.full(n_cols, -1, dtype=np.int64)
     tmark = np.full(n_cols, -1, dtype=np.int64)
-    wave_of_row = np.empty(n_rows, dtype=np.int64)
-    slot_of_row = np.empty(n_rows, dtype=np.int64)
+    wave_of_row = np.full(n_rows, -1, dtype=np.int64)     # (-1: a row outside ``order`` -- a later pass of a long-row operator)
+    slot_of_row = np.full(n_rows, -1, dtype=np.int64)
     tile_of_wave, rows = [], []
     wave, tile = -1, -1
     w_rows = w_cols = t_cols = t_waves = 0
@@ -143,9 +143,9 @@ def _bank_aware_slots(w_of_key, pos_of_key, stage, n_chunks_total, chunks):
 
 
 def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None, rows_per_wave=16):
-    """``order``: optional permutation of the rows (a locality order of the graph): rows are dealt to waves in
-    that sequence while the plan keeps addressing rows and columns by their ORIGINAL ids, so no tensor is
-    ever permuted."""
+    """``order``: optional sequence of rows (a locality order of the graph, or the subset of rows a later pass of a
+    long-row operator touches): rows are dealt to waves in that sequence -- rows outside it get no slot -- while the plan
+    keeps addressing rows and columns by their ORIGINAL ids, so no tensor is ever permuted."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
@@ -229,16 +229,71 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_u
     hdr = np.zeros((n_tiles, 64), dtype=np.int32)
     hdr[tile_of_wave, waves + w_in_tile] = rows
     rowid = np.full((n_tiles, waves, rows_per_wave), -1, dtype=np.int32)
-    all_rows = np.arange(n_rows)
-    rowid[tile_of_wave[wave_of_row], w_in_tile[wave_of_row], slot_of_row] = all_rows
+    all_rows = np.flatnonzero(wave_of_row >= 0)
+    rowid[tile_of_wave[wave_of_row[all_rows]], w_in_tile[wave_of_row[all_rows]], slot_of_row[all_rows]] = all_rows
     hdr[:, 2 * waves] = union
     rowsum = np.zeros(n_rows, dtype=np.float64)
     np.add.at(rowsum, row_of_edge, np.abs(val.astype(np.float64)))
+    n_dealt = max(1, int(all_rows.size))
     stats = dict(tiles=n_tiles, waves=n_waves, rows_per_wave=float(rows.mean()),
-                 rows_per_tile=float(n_rows / n_tiles), staged_per_row=float(union.sum() / n_rows),
+                 rows_per_tile=float(n_dealt / n_tiles), staged_per_row=float(union.sum() / n_dealt),
                  chunk_fill=float(wkey.size / (n_waves * chunks * 32)), max_union=int(union.max()))
     return SplitPlan(torch.from_numpy(hdr), torch.from_numpy(rowid), torch.from_numpy(ucol), torch.from_numpy(afr), torch.from_numpy(adr),
                      torch.from_numpy(rinv), n_tiles, n_rows, n_cols, float(rowsum.max()), stats)
+
+
+def build_split_passes(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None,
+                       rows_per_wave=16, segment=None, max_passes=12):
+    """Plans for an operator with rows LONGER than a wave's column budget (the reference's full PV-US / CER-En graphs:
+    ~740 / ~495 entries per row, config/largescale/sgp_pv.yaml + experiments/run_largescale_sgp.py:167-170): every
+    group of ``rows_per_wave`` consecutive rows has its sorted column union cut into segments of one wave's column
+    budget, pass p multiplies segment p of every group that has one and -- from the second pass on -- ADDS to the result (``plan.accumulate``; one launch per pass,
+    fixed order: reproducible sums).  Returns a list of plans (one entry for an operator
+    without long rows) or None."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    col = np.asarray(col, dtype=np.int64)
+    val = np.asarray(val, dtype=np.float32)
+    lim = dict(waves=waves, chunks=chunks, max_union=max_union, rows_per_wave=rows_per_wave)
+    one = build_split_plan(rowptr, col, val, n_rows, n_cols, order=order, **lim)
+    if one is not None:
+        return [one]
+    if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
+        return None
+    cap = int(segment or min(32 * chunks, max_union))
+    # 2-D blocking: groups of ``rows_per_wave`` consecutive rows (in dealing order) x segments of ``cap`` columns of the
+    # group's sorted column union -- every (group, segment) block fits one wave with all of the group's rows in it
+    seq = np.arange(n_rows) if order is None else np.asarray(order, dtype=np.int64)
+    group_of_row = np.full(n_rows, -1, dtype=np.int64)
+    group_of_row[seq] = np.arange(seq.size) // rows_per_wave
+    n_groups = (seq.size + rows_per_wave - 1) // rows_per_wave
+    row_of_edge = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr[:n_rows + 1]))
+    g_of_edge = group_of_row[row_of_edge]
+    gkey, ginv = np.unique(g_of_edge * n_cols + col, return_inverse=True)       # distinct (group, column) pairs, sorted
+    g_of_key = gkey // n_cols
+    first = np.searchsorted(g_of_key, np.arange(n_groups))
+    rank = np.arange(gkey.size) - first[g_of_key]                               # rank of the column in its group's union
+    pass_of_edge = (rank // cap)[ginv]
+    n_pass = int(pass_of_edge.max()) + 1
+    if n_pass > max_passes:
+        return None
+    plans = []
+    for p in range(n_pass):
+        take = pass_of_edge == p
+        cnt = np.bincount(row_of_edge[take], minlength=n_rows)
+        rp = np.zeros(n_rows + 1, dtype=np.int64)
+        rp[1:] = np.cumsum(cnt)
+        if p == 0:
+            rows_p = seq                                     # the first pass writes every row (also the empty ones)
+        else:
+            live = np.zeros(n_groups, dtype=bool)            # whole groups, so that waves stay aligned with them
+            live[np.unique(g_of_edge[take])] = True
+            rows_p = seq[live[group_of_row[seq]]]
+        plan = build_split_plan(rp, col[take], val[take], n_rows, n_cols, order=rows_p, **lim)
+        if plan is None:
+            return None
+        plan.accumulate = p > 0
+        plans.append(plan)
+    return plans
 
 
 def plan_matrix(plan, n_rows, n_cols):

@@ -44,6 +44,32 @@ def knn_graph(n, k=100, seed=1):
     return edge_index, torch.from_numpy(w.reshape(-1)), torch.from_numpy(xy.astype(np.float32))
 
 
+def threshold_graph(n, mean_degree, seed=1):
+    """The reference's FULL large-scale graphs (``adj_knn=None``: experiments/run_largescale_sgp.py:167-170 with
+    config/largescale/sgp_pv.yaml / sgp_cer.yaml): Gaussian-kernel similarities of ALL pairs with the small ones
+    cut off (tsl/ops/similarities.py:58-62 + the connectivity threshold) -- PV-US 3 710 008 edges on 5 016 nodes (~740
+    per row), CER-En 3 186 369 on 6 435 (~495).  Synthetic stand-in: n uniform points in the unit square in Morton
+    order, weights exp(-(d/theta)^2), theta = std of the pairwise distances, every pair within the radius that
+    gives ``mean_degree`` entries per row on average (self excluded); rows near the border are shorter, rows in
+    the middle longer -- ragged lengths like the real graphs."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(seed)
+    xy = rng.random((n, 2))
+    xy = xy[morton_order(xy)]
+    m = min(n, 4096)
+    smp = xy[rng.choice(n, m, replace=False)]
+    d = np.sqrt(((smp[:, None, :] - smp[None, :, :]) ** 2).sum(-1))
+    theta = d.std()
+    radius = float(np.quantile(d[np.triu_indices(m, 1)], min(1.0, mean_degree / (n - 1))))
+    tree = cKDTree(xy)
+    pairs = tree.query_pairs(radius, output_type="ndarray")               # i < j
+    src = np.concatenate([pairs[:, 0], pairs[:, 1]]).astype(np.int64)
+    dst = np.concatenate([pairs[:, 1], pairs[:, 0]]).astype(np.int64)
+    dist = np.sqrt(((xy[src] - xy[dst]) ** 2).sum(-1))
+    w = np.exp(-(dist / theta) ** 2).astype(np.float32)
+    return torch.from_numpy(np.stack([src, dst])), torch.from_numpy(w), torch.from_numpy(xy.astype(np.float32))
+
+
 def random_graph(n, k=100, seed=1):
     """k distinct uniformly random in-neighbours per node, weights U(0, 1)."""
     rng = np.random.default_rng(seed)

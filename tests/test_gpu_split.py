@@ -138,20 +138,23 @@ def test_split_time_chunks_and_run_to_run_determinism():
 
 
 def test_split_is_not_chosen_where_it_cannot_serve():
-    """Rows longer than a wave's column budget, widths that are not multiples of 16 and small graphs keep the
-    exact-fp32 kernels; ``force='split'`` says why it cannot."""
+    """Widths that are not multiples of 16, small graphs and non-finite bounds keep the exact-fp32 kernels; a row
+    longer than a wave's column budget is served in several passes (``splitplan.build_split_passes``)."""
     n = 3000
     ei, ew, _ = synthetic.knn_graph(n, 30, seed=1)
     hub = torch.stack([torch.arange(400), torch.full((400,), 5)])      # row 5 gains 400 columns
     op = graph.ShiftOperator.from_edges(torch.cat([ei, hub], 1), torch.cat([ew, torch.ones(400)]), n)
-    assert op.split_plan(torch.device("cuda")) is None
+    passes = op.split_plan(torch.device("cuda"))
+    assert isinstance(passes, list) and len(passes) >= 2 and not passes[0].accumulate and passes[1].accumulate
     x = torch.randn(2, n, 64, device="cuda")
-    y = torch.empty_like(x)
+    y = torch.full_like(x, float("nan"))
     op.propagate(x, y)
-    assert op.last_kernel != "spmm_split"
+    assert op.resolved_kernel() == "spmm_split"
     close(y, dense_ref(op, x))
-    with pytest.raises(NotImplementedError):
-        op.propagate(x, y, force="split")
+    y.fill_(float("nan"))
+    op.propagate(x, y, force="split")
+    close(y, dense_ref(op, x))
+    as_good_as_fp32(op, x, y)
     op2 = graph.ShiftOperator.from_edges(ei, ew, n)
     x20 = torch.randn(2, n, 20, device="cuda")
     op2.propagate(x20, torch.empty_like(x20))
@@ -159,6 +162,35 @@ def test_split_is_not_chosen_where_it_cannot_serve():
     op2.propagate(x, y, x_bound=float("inf"))                           # a non-finite bound falls back
     assert op2.last_kernel != "spmm_split"
     close(y, dense_ref(op2, x))
+    with pytest.raises(ValueError):
+        op2.propagate(x, y, force="split", x_bound=float("inf"))
+
+
+@pytest.mark.parametrize("n,deg", [(5016, 740), (3000, 495)])
+def test_split_long_rows_full_graph_shapes(n, deg):
+    """The reference's FULL large-scale graphs (config/largescale/sgp_pv.yaml with adj_knn=None,
+    experiments/run_largescale_sgp.py:167-170: ~740 entries per row on 5 016 nodes; CER-En ~495): every group of 16
+    rows has its column union cut into segments of one wave's budget, one launch per segment, results accumulated in
+    place.  Parity against the dense fp64 product, per column, and against the CPU fp32 product."""
+    torch.manual_seed(n)
+    ei, ew, _ = synthetic.threshold_graph(n, deg, seed=1)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    assert op.max_degree() > 256
+    passes = op.split_plan(torch.device("cuda"))
+    assert isinstance(passes, list) and len(passes) >= 3
+    assert passes[0].stats["rows_per_wave"] > 12 and passes[0].stats["staged_per_row"] < 5
+    t, feat = 5, 128
+    out = torch.randn(t, n, 3 * feat, device="cuda")
+    out[:, :, :feat] = torch.tanh(out[:, :, :feat])
+    x, y = out[:, :, :feat], out[:, :, feat:2 * feat]                   # strided slots, as the encoder uses them
+    op.propagate(x, y, x_bound=1.0)
+    assert op.resolved_kernel() == "spmm_split"
+    ref = dense_ref(op, x)
+    close(y, ref)
+    as_good_as_fp32(op, x.contiguous(), y)
+    y2 = out[:, :, 2 * feat:]
+    op.propagate(x, y2, force="mix") if op.mix_plan(feat, x.device, strict=False) is not None else op.propagate(x, y2, force="csr")
+    close(y, y2, rtol=1e-6, atol=1e-6, fro=2e-6)
 
 
 def test_split_encoder_matches_the_oracle_and_the_exact_kernels(monkeypatch):

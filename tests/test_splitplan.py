@@ -93,6 +93,27 @@ def test_rows_beyond_a_waves_budget_have_no_plan():
     assert _plan(op, chunks=10, max_union=1024) is not None
 
 
+def test_long_rows_are_cut_into_passes():
+    """Rows beyond a wave's column budget: ``build_split_passes`` cuts every 16-row group's column union into
+    segments; the passes add up to the operator, the first one holds every row, the later ones accumulate."""
+    n = 1200
+    ei, ew, _ = synthetic.threshold_graph(n, 420, seed=2)
+    op = _op(ei, ew, n)
+    assert op.max_degree() > 224 and _plan(op) is None
+    passes = splitplan.build_split_passes(op.rowptr.numpy(), op.col.numpy(), op.val.numpy(), n, n, **LIM)
+    assert passes is not None and len(passes) >= 3
+    assert not passes[0].accumulate and all(p.accumulate for p in passes[1:])
+    assert sorted(passes[0].rowid.numpy()[passes[0].rowid.numpy() >= 0].tolist()) == list(range(n))
+    assert passes[0].stats["rows_per_wave"] > 12
+    dense = op.to_dense().numpy().astype(np.float64)
+    got = sum(splitplan.plan_matrix(p, n, n) for p in passes)
+    assert np.abs(got - dense).max() <= 2.0 ** -21 * np.abs(dense).max()
+    # an operator without long rows is one pass, the plan build_split_plan makes
+    ei, ew, _ = synthetic.knn_graph(700, 20, seed=3)
+    one = splitplan.build_split_passes(*( _op(ei, ew, 700).rowptr.numpy(), _op(ei, ew, 700).col.numpy(), _op(ei, ew, 700).val.numpy()), 700, 700, **LIM)
+    assert len(one) == 1 and not one[0].accumulate
+
+
 def test_small_budgets_cut_waves_and_tiles():
     ei, ew, _ = synthetic.knn_graph(900, 40, seed=5)
     op = _op(ei, ew, 900)

@@ -249,6 +249,41 @@ def verify_output(enc, ops, x, out, w, T, tc, d_h):
     return rec
 
 
+def verify_partitioned(enc, ops, spatial, x, out, state_used, w, T, tc, bounds, order, rank, world, backend, dev):
+    """N > 1: the first steps of every rank's TIMED rows against a single-rank recompute of those rows.  The ranks'
+    inputs of those steps are gathered into the global tensor (caller's node order), every rank encodes it alone on
+    its own device with the unpartitioned operators (no collectives) and compares its own rows (north_star tolerance
+    1e-5); the verdict is the AND over the ranks."""
+    n8 = min(8, T)
+    N, F = w["N"], x.shape[2]
+    lo, hi = bounds[rank], bounds[rank + 1]
+    rows_max = max(bounds[r + 1] - bounds[r] for r in range(world))
+    cpu = backend != "nccl"
+    mine = torch.zeros(n8, rows_max, F, device="cpu" if cpu else dev)
+    mine[:, :hi - lo] = x[:n8].to(mine.device)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    full = torch.empty(n8, N, F, device=dev)
+    for r in range(world):
+        a, b = bounds[r], bounds[r + 1]
+        ids = torch.arange(a, b, device=dev) if order is None else order[a:b].to(dev)
+        full[:, ids] = parts[r][:, :b - a].to(dev)
+    ref = enc.encode_device(full, ops)
+    ids = torch.arange(lo, hi, device=dev) if order is None else order[lo:hi].to(dev)
+    want = ref[:, ids]
+    if tc < T:                                             # ring buffer holds the last chunk: encode the prefix again (collective)
+        head = torch.empty(n8, hi - lo, out.shape[2], device=dev)
+        partition.encode_partitioned(enc.reservoir, spatial, x[:n8].contiguous(), head, None)
+    else:
+        head = out[:n8]
+    err = float((head - want).abs().max())
+    ok = bool(torch.allclose(head, want, rtol=1e-5, atol=1e-5))
+    t = torch.tensor([1.0 if ok else 0.0, -err], dtype=torch.float64, device="cpu" if cpu else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return {"ok": bool(t[0].item() == 1.0), "first_steps_vs_single_rank_max_abs": float(-t[1].item()), "steps": n8,
+            "rows": "every rank's own rows, against a single-rank recompute from the gathered inputs"}
+
+
 def relaunch(args):
     """``python bench.py --gpus N`` without a launcher: run N ranks of this file under
     torch.distributed.run on 127.0.0.1 and pass their one JSON line through."""
@@ -412,6 +447,9 @@ def main():
             torch.save(out.cpu(), os.path.join(dump, f"out_w{world}_r{rank}.pt"))
         if order is not None and rank == 0:
             torch.save(dict(order=order, bounds=bounds), os.path.join(dump, f"order_w{world}.pt"))
+    verify_multi = None
+    if world > 1 and spatial is not None and not args.no_verify:
+        verify_multi = verify_partitioned(enc, ops, spatial, x, out, state, w, T, tc, bounds, order, rank, world, backend, dev)
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = N * T * args.steps / elapsed
@@ -499,6 +537,9 @@ def main():
         if world == 1 and spatial is None and not args.no_verify:
             rec["verify"] = verify_output(enc, ops, x, out, w, T, tc, d_h)
             rec["verified"] = bool(rec["verify"]["ok"])
+        if verify_multi is not None:
+            rec["verify"] = verify_multi
+            rec["verified"] = bool(verify_multi["ok"])
         if hop_ms and want_exact_line:
             rec["roofline_exact_fp32"] = exact_hop_line(ops[0], out, d_h, exact_bts)
         if not args.no_cpu_baseline and world == 1:

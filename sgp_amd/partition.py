@@ -98,7 +98,7 @@ def _halo_of(op, lo, hi):
     return torch.unique(outside, sorted=True), cols
 
 
-def split_operator(op: ShiftOperator, bounds, rank, exchange="packed") -> LocalBlock:
+def split_operator(op: ShiftOperator, bounds, rank, exchange="packed", halos=None) -> LocalBlock:
     """Local block of ``rank`` plus the halo bookkeeping, computed from the full operator
     (every rank holds the whole graph: it is tiny next to the node features).
     ``exchange``: "packed" (default here) = all_to_all of the rows peers reference, "gather" =
@@ -107,8 +107,8 @@ def split_operator(op: ShiftOperator, bounds, rank, exchange="packed") -> LocalB
     figure, so all take the same branch)."""
     world = len(bounds) - 1
     lo, hi = bounds[rank], bounds[rank + 1]
-    halo, cols = _halo_of(op, lo, hi)
-    n_own = hi - lo
+    halo, cols = _halo_of(op, lo, hi)                               # (``halos``: every rank's halo list, computed once
+    n_own = hi - lo                                                 # by ``plan_partition`` when one process cuts all blocks)
     own = (cols >= lo) & (cols < hi)
     rp = op.rowptr.long()
     rowptr = rp[lo:hi + 1] - rp[lo]
@@ -122,7 +122,7 @@ def split_operator(op: ShiftOperator, bounds, rank, exchange="packed") -> LocalB
         if p == rank:
             send_counts.append(0)
             continue
-        ph, _ = _halo_of(op, bounds[p], bounds[p + 1])
+        ph = halos[p] if halos is not None else _halo_of(op, bounds[p], bounds[p + 1])[0]
         halo_total += int(ph.numel())
         mine = ph[(ph >= lo) & (ph < hi)] - lo
         send_idx.append(mine)
@@ -416,25 +416,9 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     return out
 
 
-def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
-                             rank=None, world_size=None, group=None, ops=HipOps,
-                             balance="nnz", n_chunks=4, force_collectives=False, locality="auto",
-                             exchange="auto"):
-    """Split the forward (and backward) global operators for this rank.
-
-    Returns ``(spatial, bounds)``; ``spatial.node_order`` is None when rank r owns the global
-    nodes ``bounds[r] .. bounds[r+1]``, else an int64 tensor and rank r owns
-    ``node_order[bounds[r]:bounds[r+1]]`` (in that order: row i of the rank's tensors is global
-    node ``node_order[bounds[r] + i]``).  ``locality``: "auto" renumbers the nodes by
-    ``graph.locality_order`` when a contiguous cut of the given numbering would make a rank fetch
-    more than half as many halo rows as it owns (a k-NN graph of stations in file order:
-    near-full exchange) and the renumbering fetches at least 30 % fewer; "never" keeps the
-    numbering; "always" renumbers.
-    ``balance``: "nnz" cuts equal edge counts (equal SpMM work), "rows" equal row counts.
-    ``exchange``: see ``split_operator`` ("auto": all_gather of full shards instead of the packed
-    all_to_all when the ranks together reference more than half of all remote rows)."""
-    rank = dist.get_rank(group) if rank is None else rank
-    world_size = dist.get_world_size(group) if world_size is None else world_size
+def choose_numbering(ops_global: List[ShiftOperator], world_size, balance="nnz", locality="auto"):
+    """Row bounds of the ranks and, for numberings without locality, the renumbering that gives the cut compact halos:
+    ``(ops_global or their permuted forms, bounds, node_order or None)`` (see ``make_partitioned_spatial``)."""
     n = ops_global[0].num_nodes
 
     def cut(op_list):
@@ -458,7 +442,66 @@ def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, g
                     import warnings
                     warnings.warn("make_partitioned_spatial: the node numbering has no locality; rank r owns "
                                   "spatial.node_order[bounds[r]:bounds[r+1]], not the contiguous range "
-                                  "(pass locality='never' to keep the numbering)", stacklevel=2)
+                                  "(pass locality='never' to keep the numbering)", stacklevel=3)
+    return ops_global, bounds, node_order
+
+
+@dataclass
+class PartitionPlan:
+    """Everything the ranks of a node partition need, cut ONCE (``plan_partition``): row bounds, the renumbering (or
+    None), the global operators' infinity norms and every rank's local blocks (one per direction)."""
+    bounds: List[int]
+    node_order: Optional[torch.Tensor]
+    norm_inf: List[float]
+    n_total: int
+    rank_blocks: List[List[LocalBlock]]
+
+
+def plan_partition(ops_global: List[ShiftOperator], world_size, balance="nnz", locality="auto", exchange="auto"):
+    """Cut the global operators for ALL ranks in one process (``multigpu.encode_multi_gpu`` does it in the parent and
+    hands every rank its own blocks: the graph preparation, the locality order and the halo lists are computed once
+    instead of once per rank)."""
+    ops_global, bounds, node_order = choose_numbering(ops_global, world_size, balance, locality)
+    rank_blocks = [[] for _ in range(world_size)]
+    for op in ops_global:
+        halos = [_halo_of(op, bounds[p], bounds[p + 1])[0] for p in range(world_size)]
+        for r in range(world_size):
+            rank_blocks[r].append(split_operator(op, bounds, r, exchange=exchange, halos=halos))
+    return PartitionPlan([int(b) for b in bounds], node_order, [op.norm_inf() for op in ops_global],
+                         ops_global[0].num_nodes, rank_blocks)
+
+
+def spatial_from_plan(plan: PartitionPlan, rank, receptive_field, global_attr, group=None, ops=HipOps, n_chunks=4,
+                      force_collectives=False):
+    """This rank's ``PartitionedSpatial`` from a ``PartitionPlan`` cut elsewhere."""
+    spatial = PartitionedSpatial(plan.rank_blocks[rank], receptive_field, global_attr, plan.n_total, group, ops,
+                                 n_chunks=n_chunks, force_collectives=force_collectives)
+    spatial.node_order = plan.node_order
+    spatial.norm_inf = list(plan.norm_inf)
+    return spatial
+
+
+def make_partitioned_spatial(ops_global: List[ShiftOperator], receptive_field, global_attr,
+                             rank=None, world_size=None, group=None, ops=HipOps,
+                             balance="nnz", n_chunks=4, force_collectives=False, locality="auto",
+                             exchange="auto"):
+    """Split the forward (and backward) global operators for this rank.
+
+    Returns ``(spatial, bounds)``; ``spatial.node_order`` is None when rank r owns the global
+    nodes ``bounds[r] .. bounds[r+1]``, else an int64 tensor and rank r owns
+    ``node_order[bounds[r]:bounds[r+1]]`` (in that order: row i of the rank's tensors is global
+    node ``node_order[bounds[r] + i]``).  ``locality``: "auto" renumbers the nodes by
+    ``graph.locality_order`` when a contiguous cut of the given numbering would make a rank fetch
+    more than half as many halo rows as it owns (a k-NN graph of stations in file order:
+    near-full exchange) and the renumbering fetches at least 30 % fewer; "never" keeps the
+    numbering; "always" renumbers.
+    ``balance``: "nnz" cuts equal edge counts (equal SpMM work), "rows" equal row counts.
+    ``exchange``: see ``split_operator`` ("auto": all_gather of full shards instead of the packed
+    all_to_all when the ranks together reference more than half of all remote rows)."""
+    rank = dist.get_rank(group) if rank is None else rank
+    world_size = dist.get_world_size(group) if world_size is None else world_size
+    n = ops_global[0].num_nodes
+    ops_global, bounds, node_order = choose_numbering(ops_global, world_size, balance, locality)
     blocks = [split_operator(op, bounds, rank, exchange=exchange) for op in ops_global]
     spatial = PartitionedSpatial(blocks, receptive_field, global_attr, n, group, ops,
                                  n_chunks=n_chunks, force_collectives=force_collectives)

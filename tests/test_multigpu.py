@@ -33,7 +33,76 @@ def test_rank_rows_and_chunk_steps():
     assert multigpu.chunk_steps(1000, 100, 3, 320, 10 ** 9) == 1000
     assert multigpu.chunk_steps(1000, 100000, 64, 320, 2 * 10 ** 9) == 8          # the floor
     tc = multigpu.chunk_steps(1000, 10000, 64, 320, 10 ** 9)
-    assert 8 <= tc < 1000 and 2 * tc * 10000 * 384 * 4 <= 10 ** 9
+    assert 8 <= tc < 1000 and 4 * tc * 10000 * 384 * 4 <= 10 ** 9       # two input + two embedding slots
+
+
+def test_partition_plan_cut_once_equals_every_ranks_own_cut():
+    """``plan_partition`` (one process cuts all ranks' blocks: what ``encode_multi_gpu`` does in the parent) gives
+    every rank exactly the blocks ``make_partitioned_spatial`` computes for itself -- also under a locality
+    renumbering -- and the blocks survive the trip through ``torch.save``."""
+    import io
+    import warnings
+    from sgp_amd import partition
+    from sgp_amd.sgp_preprocessing import spatial_operators
+    for scramble in (False, True):
+        n, world = 900, 3
+        ei, ew, _ = synthetic.knn_graph(n, 12, seed=4)
+        if scramble:
+            ei = torch.randperm(n, generator=torch.Generator().manual_seed(0))[ei]
+        ops = spatial_operators(ei, ew, n, bidirectional=True)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            plan = partition.plan_partition(ops, world)
+            assert (plan.node_order is not None) == scramble
+            buf = io.BytesIO()
+            torch.save(plan.rank_blocks[1], buf)
+            buf.seek(0)
+            loaded = torch.load(buf, weights_only=False)
+            for r in range(world):
+                sp, bounds = partition.make_partitioned_spatial(ops, 2, False, rank=r, world_size=world,
+                                                                ops=partition.HipOps)
+                assert [int(b) for b in bounds] == plan.bounds
+                for mine, theirs in zip(plan.rank_blocks[r] if r != 1 else loaded, sp.blocks):
+                    assert (mine.lo, mine.hi, mine.gather_rows) == (theirs.lo, theirs.hi, theirs.gather_rows)
+                    assert torch.equal(mine.op.rowptr, theirs.op.rowptr) and torch.equal(mine.op.col, theirs.op.col)
+                    assert torch.equal(mine.op.val, theirs.op.val) and mine.op.num_cols == theirs.op.num_cols
+                    assert torch.equal(mine.halo_global, theirs.halo_global)
+                    assert torch.equal(mine.send_index, theirs.send_index)
+                    assert mine.send_counts == theirs.send_counts and mine.recv_counts == theirs.recv_counts
+                assert sp.norm_inf == plan.norm_inf
+
+
+@pytest.mark.gpu
+def test_rank_pipeline_overlaps_transfers_with_the_next_chunk():
+    """The per-rank time-chunk pipeline: the D2H of chunk i runs while the device already encodes chunk i + 1 (event
+    times), the host gather / scatter never sits between two chunks' compute, and the data arrive intact."""
+    import time
+    dev = torch.device("cuda", 0)
+    T, tc, n_own, f_in, d_out = 48, 8, 4000, 16, 1024
+    x = torch.randn(T, 2 * n_own, f_in)
+    rows = torch.arange(0, 2 * n_own, 2)
+    got = torch.zeros(T, n_own, d_out)
+
+    def encode(xs, oc):                                            # ~15 ms of device work per chunk, only enqueued
+        torch.cuda._sleep(30_000_000)
+        oc.copy_(xs.repeat(1, 1, d_out // f_in))
+
+    def sink(t0, n, emb):
+        got[t0:t0 + n] = emb
+
+    pipe = multigpu.RankPipeline(dev, tc, n_own, f_in, d_out)
+    events = []
+    t0 = time.perf_counter()
+    pipe.run(x, rows, T, encode, sink, events)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    assert torch.equal(got, x[:, rows].repeat(1, 1, d_out // f_in))
+    comp = [a.elapsed_time(b) for a, b, _ in events]
+    d2h_after_next_start = [events[i + 1][0].elapsed_time(events[i][2]) for i in range(len(events) - 1)]
+    gaps = [events[i][1].elapsed_time(events[i + 1][0]) for i in range(len(events) - 1)]
+    assert min(d2h_after_next_start) > 0, d2h_after_next_start      # chunk i leaves while chunk i + 1 is being encoded
+    assert max(gaps[1:]) < 0.5 * min(comp), (gaps, comp)            # nothing (host copies, D2H) between two chunks' compute
+    assert wall * 1e3 < sum(comp) + 3 * max(comp), (wall, comp)
 
 
 def test_gpus_argument_is_rejected_where_it_cannot_be_served():

@@ -133,7 +133,7 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     const int jt = pick_jt(R), nkx = pick_nkx(F);
     if (!jt || !nkx) return -1;
     // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
-    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
+    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
            (sbf3_supported(jt, nkx) ? sbf3_packed_bytes(jt, nkx) + 1024 : 0);     // + dump area of the kernel
 }
 
@@ -166,7 +166,9 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     a.wp_bf3 = nullptr;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
-    if (use_bf3 && bf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) {
+    // (the split-J form for small N -- R = 64 / 128, up to 32 input features -- takes any R <= 16 jt, F <= 4 nkx: padded
+    // units and features carry zero weights; the large-N form needs the exact widths)
+    if (use_bf3 && ((bf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) || sjbf3_supported(jt, nkx))) {
         char* wb = (char*)workspace + bf3_offset(jt, nkx);
         const int threads = jt * (bf3_kbh(jt) + bf3_kbx(nkx)) * 64;
         hipLaunchKernelGGL(pack_weights_bf3, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wb, F, R, jt, nkx);

@@ -1228,6 +1228,8 @@ int launch_layer(ResArgs a, hipStream_t s) {
 
 template <int JT, int NKX> int launch_stream_ool(const ResArgs& a, hipStream_t s);   // reservoir_stream.hip
 
+#include "reservoir_splitj_bf3.h"
+
 // experiment knobs (SGP_TUNE, read once): res_splitj_max = largest tile count served by the split-J kernel
 // alone, res_tail = 0 disables the exact deal + split-J tail of large problems
 
@@ -1236,6 +1238,18 @@ int launch_splitj(const ResArgs& a, int n_tiles, hipStream_t s) {
     ResArgs b = a;
     b.n_tiles = n_tiles;
     const bool ov = (a.R % 4 == 0) && (a.ors % 4 == 0) && (a.oss % 4 == 0) && sgp::aligned16(a.out);
+    if constexpr (sjbf3_supported(JT, NKX) && sjbf3_lds_bytes(JT, NKX) <= kLdsLimit) {
+        // three-piece bf16 products (reservoir_splitj_bf3.h): the step is no longer bound by the fp32 matrix pipe
+        if (a.wp_bf3) {
+            auto kern = ov ? reservoir_layer_splitj_bf3<JT, NKX, true> : reservoir_layer_splitj_bf3<JT, NKX, false>;
+            const int bytes = (int)sjbf3_lds_bytes(JT, NKX);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), (size_t)bytes, s, b);
+            return sgp::check_launch("reservoir_layer_splitj_bf3");
+        }
+    }
     auto kern = ov ? reservoir_layer_splitj<JT, NKX, true> : reservoir_layer_splitj<JT, NKX, false>;
     const int bytes = (int)splitj_lds_bytes<JT, NKX>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),

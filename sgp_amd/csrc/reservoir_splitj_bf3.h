@@ -1,0 +1,267 @@
+// Small-N leaky echo-state layer on the 16-bit matrix cores with fp32-grade products (included by reservoir_impl.h
+// inside namespace sgp_res behind reservoir_bf3.h; reference: lib/nn/reservoir/reservoir.py:77-81 stepped by :170-183 at
+// the traffic configs' shapes, config/traffic/sgp_la.yaml R = 64 / sgp_bay.yaml R = 128, N = 207 / 325, F = 3).
+//
+// With a few hundred nodes the layer is one serial chain of T steps on a dozen node tiles.  reservoir_layer_splitj cuts
+// a step's output tiles over the 4 waves of a workgroup (one per SIMD) and is then bound by the fp32 matrix pipe inside
+// every SIMD: R = 128 needs 66 v_mfma_f32_16x16x4_f32 of 32 cycles per wave and step (2112 of the step's ~3400
+// cycles; BENCH r4: C2 spends 86 of 92 ms here, C1 21 of 22).  This kernel keeps that structure -- one node tile per
+// workgroup, JT / 4 output tiles per wave, the new state exchanged through a double-buffered LDS slab, one barrier per
+// step, input rows by LDS-DMA into a ring, stores at the top of the next step -- and forms the products as in
+// reservoir_bf3.h: every fp32 operand as THREE bf16 pieces (24 bits, no scale, any activation), six piece products of
+// order <= 2^-16 on v_mfma_f32_16x16x32_bf16 with fp32 accumulation: R = 128: 60 MFMAs of 16 cycles per wave and step.
+//
+// What travels through the slab are the PIECES: a wave splits the 4 new values a lane holds of each of its tiles
+// (bf3_split2 twice) and writes them where the consumers' B operand of k-block p = tile / 2 expects them (8 bytes per
+// lane and piece at [piece][p][lane][tile & 1]: one ds_read_b128 per k-block and piece on the reading side); the fp32
+// state of a wave's OWN tiles stays in its registers for the leak.  The weight fragments are those of
+// pack_weights_bf3 (k order of the recurrent blocks = the accumulator layout, reservoir_bf3.h); a wave keeps the fragments
+// of its own output tiles in REGISTERS for the whole sequence (one wave per SIMD: 120 of 512 registers at R = 128).
+// The accumulation of a tile is cut into independent chains (added at the end) with the chain index as the inner
+// loop, so that no MFMA waits for the result of the one before it.
+//
+// Widths: R <= 16 JT, F <= 4 NKX with NKX <= 8 (one input k-block), any N, T; padded units / features carry zero
+// weights and zero operands, stores are masked like the fp32 kernel's.
+
+__host__ __device__ constexpr bool sjbf3_supported(int JT, int NKX) { return (JT == 4 || JT == 8) && NKX <= 8; }
+// LDS: piece slab [2][3][KBH][64][16 B] | self_norm partials [2][64] | input ring [PFD][NKX][64]
+__host__ __device__ constexpr long long sjbf3_slab_bytes(int JT) { return 2ll * 3 * bf3_kbh(JT) * 1024; }
+__host__ __device__ constexpr int sjbf3_ring(int JT, int NKX) { return 8; }
+__host__ __device__ constexpr long long sjbf3_lds_bytes(int JT, int NKX) {
+    return sjbf3_slab_bytes(JT) + 2 * 64 * 4 + (long long)sjbf3_ring(JT, NKX) * NKX * 256;
+}
+
+// experiment switches (build with -DSGP_SJ_ABL=bits): 1 no result stores, 2 wave 0's row wait counts its stores too,
+// 4 no row wait at all (wrong results), 8 no activation, 16 no piece exchange (wrong results), 32 no MFMAs
+#ifndef SGP_SJ_ABL
+#define SGP_SJ_ABL 0
+#endif
+constexpr bool sj_abl(int bit) { return (SGP_SJ_ABL & bit) != 0; }
+
+template <int JT, int NKX, bool OVEC>
+__global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
+    static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one input k-block");
+    constexpr int JW = JT / 4;                           // output tiles per wave
+    constexpr int KBH = bf3_kbh(JT), KB = KBH + 1;       // recurrent k-blocks (two state tiles each) + the input block
+    constexpr int PFD = sjbf3_ring(JT, NKX);
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* slab = lds_raw;                                                  // [2][3][KBH][64][16]
+    float* red_base = reinterpret_cast<float*>(slab + sjbf3_slab_bytes(JT));
+    float* xring = red_base + 2 * 64;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n_in = lane & 15, q = lane >> 4;
+    const int node = blockIdx.x * 16 + n_in;
+    const bool ok = node < a.N;
+
+    // fp32 state of this wave's own tiles (leak), zero in padded units
+    f32x4 hown[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) {
+        const int j0 = 16 * (wave * JW + w) + 4 * q;
+        float hv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.h_state && ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (j0 + r < a.R) hv[r] = a.h_state[(long long)node * a.R + j0 + r];
+        }
+        hown[w] = f32x4{hv[0], hv[1], hv[2], hv[3]};
+    }
+    // pieces of a tile's 4 values -> the slab of parity `par`
+    auto publish = [&](int par, int w, const f32x4 hv) {
+        const int jt = wave * JW + w;
+        unsigned a1, a2, a3, b1, b2, b3;
+        bf3_split2(hv[0], hv[1], a1, a2, a3);
+        bf3_split2(hv[2], hv[3], b1, b2, b3);
+        char* base = slab + (size_t)par * (3 * KBH * 1024) + (size_t)(jt >> 1) * 1024 + lane * 16 + (jt & 1) * 8;
+        *reinterpret_cast<uint2*>(base) = uint2{a1, b1};
+        *reinterpret_cast<uint2*>(base + KBH * 1024) = uint2{a2, b2};
+        *reinterpret_cast<uint2*>(base + 2 * KBH * 1024) = uint2{a3, b3};
+    };
+
+    // input rows: lane (n, q) register ks <-> feature bf3_feature(NKX, q, ks), as pack_weights_bf3 orders the input block
+    bool x_ok[NKX];
+    long long x_off[NKX];
+    {
+        const int nodec = min(node, a.N - 1);
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) {
+            const int f = bf3_feature(NKX, q, ks);
+            x_ok[ks] = ok && f < a.F;
+            x_off[ks] = (long long)nodec * a.xrs + min(f, a.F - 1);
+        }
+    }
+    const unsigned xring_lds = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) float*)xring);
+    auto dma_x = [&](int t) {
+        const float* xp = a.x + (long long)min(t, a.T - 1) * a.xss;
+        const unsigned base = xring_lds + (unsigned)((t % PFD) * NKX * 256);
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) {
+            const float* src = xp + x_off[ks];
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
+                         :: "v"(src), "s"(base + (unsigned)ks * 256u) : "memory");
+        }
+    };
+    bool st_ok[JW];
+#pragma unroll
+    for (int w = 0; w < JW; ++w) st_ok[w] = ok && 16 * (wave * JW + w) + 4 * q < a.R;
+    auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            const int j0 = 16 * (wave * JW + w) + 4 * q;
+            if (st_ok[w]) {
+                float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
+                if constexpr (OVEC) {
+                    *reinterpret_cast<f32x4*>(op) = hv[w];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (j0 + r < a.R) op[r] = hv[w][r];
+                }
+            }
+        }
+    };
+    // this wave's weight fragments and bias: ONE wave per SIMD owns the whole register file, so the 3 KB x KB x 3 pieces
+    // of its JW output tiles stay resident for all T steps (the fp32 form re-reads them from LDS every step)
+    u32x4 W[JW][KB][3];
+    f32x4 bias[JW];
+    {
+        const char* wp = reinterpret_cast<const char*>(a.wp_bf3);
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            bias[w] = *reinterpret_cast<const f32x4*>(wp + ((wave * JW + w) * 16 + q * 4) * 4);
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    W[w][kb][pc] = *reinterpret_cast<const u32x4*>(wp + JT * 64 + bf3_frag_off(KB, wave * JW + w, kb, pc) + lane * 16);
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), visible to the compiler: state and weights have landed
+#pragma unroll
+    for (int w = 0; w < JW; ++w) publish(1, w, hown[w]);  // step 0 reads parity 1
+    __syncthreads();                                     // initial pieces in LDS
+    if (wave == 0) {
+        for (int p = 0; p < PFD - 1; ++p) dma_x(p);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // rows 0 .. PFD-2 published
+
+    // pieces of the input row of step 0 (rows 0 .. PFD - 2 are published)
+    u32x4 X[3];
+    auto input_pieces = [&](int t) {
+        const float* xrow = xring + (t % PFD) * NKX * 64;
+        float xv[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xv[ks] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < NKX; ++ks) xv[ks] = x_ok[ks] ? xrow[ks * 64 + lane] : 0.f;
+        bf3_split8(xv, X[0], X[1], X[2]);
+    };
+    input_pieces(0);
+
+    for (int t = 0; t < a.T; ++t) {
+        if (t > 0 && !sj_abl(1)) store_h(t - 1, hown);
+        if (wave == 0) dma_x(t + PFD - 1);               // into the slot consumed one step ago
+        // B operands: the state pieces of step t - 1 (all tiles); the input pieces were prepared during step t - 1
+        u32x4 V[KB][3];
+        {
+            const char* sp = slab + (size_t)((t & 1) ^ 1) * (3 * KBH * 1024) + lane * 16;
+#pragma unroll
+            for (int p = 0; p < KBH; ++p)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+                    V[p][pc] = *reinterpret_cast<const u32x4*>(sp + (pc * KBH + p) * 1024);
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) V[KBH][pc] = X[pc];
+        }
+        // One accumulation chain per (output tile, k-block), added at the end; the six piece products (smallest first,
+        // reservoir_bf3.h) are the OUTER loop, so that consecutive MFMAs never wait for each other's result.  Measured
+        // (N = 325, R = 128 / N = 207, R = 64, us per step): this order 1.12 / 0.55; a k-block's six products back to back
+        // on one accumulator 1.41 / 0.66; tile by tile (5 chains at a time, the tail of tile 0 under the MFMAs of tile 1)
+        // 1.27 / 0.60; the six products of a k-block as two chains of three 1.23 / 0.65.
+        f32x4 acc[JW][KB];
+#pragma unroll
+        for (int w = 0; w < JW; ++w)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) acc[w][kb] = kb == KBH ? bias[w] : f32x4{0.f, 0.f, 0.f, 0.f};
+        constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};     // W3 V1, W2 V2, W1 V3, W2 V1, W1 V2, W1 V1
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int w = 0; w < JW; ++w)
+                    if (!sj_abl(32)) acc[w][kb] = bf3_mfma(W[w][kb][PW[i]], V[kb][PV[i]], acc[w][kb]);
+        // the input row of step t + 1 is visible since the last barrier (wave 0 retires rows two steps ahead): its pieces
+        // are cut here, in the shadow of the MFMAs
+        if (t + 1 < a.T) input_pieces(t + 1);
+        f32x4 pre[JW];
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            pre[w] = acc[w][KBH];
+#pragma unroll
+            for (int kb = 0; kb < KBH; ++kb) pre[w] += acc[w][kb];
+        }
+        if (a.act == SGP_ACT_TANH && !sj_abl(8)) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[w][r] = tanh_r(pre[w][r]);
+        } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[w][r] = fmaxf(pre[w][r], 0.f);
+        }
+        if (a.act == SGP_ACT_SELF_NORM) {
+            // norm over all R features: partial sums of the 4 waves meet in LDS
+            float ss = 0.f;
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ss = fmaf(pre[w][r], pre[w][r], ss);
+            ss += __shfl_xor(ss, 16);
+            ss += __shfl_xor(ss, 32);
+            float* red = red_base + (t & 1) * 64;
+            if (q == 0) red[wave * 16 + n_in] = ss;
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const float tot = red[n_in] + red[16 + n_in] + red[32 + n_in] + red[48 + n_in];
+            const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pre[w][r] *= inv;
+        }
+        // leak, publish the pieces of my tiles (the fp32 values are stored to HBM at the top of the next step)
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            f32x4 hn;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                hn[r] = a.act == SGP_ACT_TANH ? leak_tanh_r(hown[w][r], pre[w][r], a.alpha, a.one_minus_alpha)
+                                              : leak(hown[w][r], pre[w][r], a.alpha, a.one_minus_alpha);
+            hown[w] = hn;
+            if (!sj_abl(16)) publish(t & 1, w, hn);
+        }
+        // wave 0: the row of step t + 2 has landed once at most the (PFD - 3) NKX younger requests
+        // (+ this step's stores, which only make the wait stricter) are outstanding
+        if (wave == 0 && !sj_abl(4)) {
+            constexpr int kOps = sj_abl(2) ? (PFD - 3) * (NKX + JW) : (PFD - 3) * NKX;
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(kOps < 63 ? kOps : 63) : "memory");
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+    if (a.T > 0) store_h(a.T - 1, hown);
+    if (a.h_state) {
+#pragma unroll
+        for (int w = 0; w < JW; ++w) {
+            const int j0 = 16 * (wave * JW + w) + 4 * q;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ok && j0 + r < a.R) a.h_state[(long long)node * a.R + j0 + r] = hown[w][r];
+        }
+    }
+}

@@ -117,3 +117,34 @@ def test_bf3_wide_reservoir_short_sequences_strided_rows_and_state(t):
     out = wide[:, :, 64:64 + r]
     assert torch.equal(state[0], out[-1])
     check(out, x, res, "tanh", [0, 5, 16 * 1000 + 3, n - 20, n - 2, n - 1])
+
+
+@pytest.mark.parametrize("n,f,r,act,t", [
+    (207, 3, 64, "tanh", 300),          # METR-LA shape (C1): 13 node tiles, one output tile per wave
+    (325, 3, 128, "tanh", 300),         # PEMS-BAY shape (C2): two output tiles per wave
+    (325, 3, 128, "relu", 120),
+    (207, 3, 64, "self_norm", 120),
+    (500, 5, 100, "tanh", 60),          # padded units (R = 100 of 128) and features (F = 5 of 8)
+    (77, 20, 50, "tanh", 60),           # F = 20: the 16-byte feature order of the wider input blocks; ragged last tile
+    (8190, 3, 64, "tanh", 40),          # 512 node tiles: the largest problem the split-J form serves alone
+    (1000, 32, 128, "tanh", 40),        # a full input k-block
+])
+def test_split_j_bf3_small_graphs(n, f, r, act, t):
+    """The small-N form (reservoir_splitj_bf3.h: one node tile per workgroup, the output tiles split over its four
+    waves, the state exchanged as bf16 pieces through LDS) at the traffic configs' shapes: as close to fp64 as the
+    CPU's fp32 run, every activation, padded widths, and the state carried across calls."""
+    hip.require_gpu()
+    torch.manual_seed(n + r)
+    res = sgp_amd.Reservoir(f, r, activation=act, spectral_radius=0.5 if act == "relu" else 0.9)
+    x = torch.randn(t, n, f)
+    out = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x.cuda(), out)
+    assert torch.isfinite(out).all()
+    check(out, x, res, act, sorted({0, 1, 15, 16, n // 2, n - 2, n - 1}))
+    state = torch.zeros(1, n, r, device="cuda")
+    wide = torch.zeros(t, n, r + 8, device="cuda")
+    res.encode_into(x[:t // 3].cuda(), wide[:t // 3, :, 4:4 + r], state)
+    res.encode_into(x[t // 3:].cuda(), wide[t // 3:, :, 4:4 + r], state)
+    assert torch.equal(wide[:, :, 4:4 + r], out)                       # same bits whatever the cut, strided rows
+    assert float(wide[:, :, :4].abs().max()) == 0.0 and float(wide[:, :, 4 + r:].abs().max()) == 0.0
+    assert torch.equal(state[0], out[-1])

@@ -27,13 +27,22 @@ __global__ __launch_bounds__(256) void col_stats_kernel(const float* x, long lon
     unsigned m[4] = {0, 0, 0, 0};
     float s[4] = {0.f, 0.f, 0.f, 0.f};
     if (r0 < rpi) {
-        for (long long r = (long long)blockIdx.x * rpi + r0; r < n_rows; r += (long long)gridDim.x * rpi) {
-            const float4 v = *(const float4*)(xb + r * xrs + 4 * c);
+        auto take = [&](const float4 v) {
             m[0] = max(m[0], __float_as_uint(fabsf(v.x))); s[0] = fmaf(v.x, v.x, s[0]);
             m[1] = max(m[1], __float_as_uint(fabsf(v.y))); s[1] = fmaf(v.y, v.y, s[1]);
             m[2] = max(m[2], __float_as_uint(fabsf(v.z))); s[2] = fmaf(v.z, v.z, s[2]);
             m[3] = max(m[3], __float_as_uint(fabsf(v.w))); s[3] = fmaf(v.w, v.w, s[3]);
+        };
+        const long long step = (long long)gridDim.x * rpi;
+        long long r = (long long)blockIdx.x * rpi + r0;
+        for (; r + 3 * step < n_rows; r += 4 * step) {          // four rows in flight per thread
+            const float4 v0 = *(const float4*)(xb + r * xrs + 4 * c);
+            const float4 v1 = *(const float4*)(xb + (r + step) * xrs + 4 * c);
+            const float4 v2 = *(const float4*)(xb + (r + 2 * step) * xrs + 4 * c);
+            const float4 v3 = *(const float4*)(xb + (r + 3 * step) * xrs + 4 * c);
+            take(v0); take(v1); take(v2); take(v3);
         }
+        for (; r < n_rows; r += step) take(*(const float4*)(xb + r * xrs + 4 * c));
     }
     __shared__ unsigned pm[256][4];
     __shared__ float ps[256][4];
@@ -112,7 +121,7 @@ int sgp_col_stats_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stri
     SGP_REQUIRE(ns <= 65535, "sgp_col_stats_f32: more than 65535 sampled steps");
     const int rpi = 256 / (feat / 4);
     long long gx = ((long long)n_rows + rpi - 1) / rpi;
-    const long long cap = 4096 / ns > 0 ? 4096 / ns : 1;       // a few thousand workgroups, 16+ rows per thread where there are
+    const long long cap = 2048 / ns > 0 ? 2048 / ns : 1;       // a couple of thousand workgroups, 16+ rows per thread where there are
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, (unsigned)ns), dim3(256), 0, s,
                        X, (long long)x_row_stride, (long long)x_batch_stride, n_rows, t_stride, feat,

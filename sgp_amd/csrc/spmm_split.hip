@@ -82,8 +82,13 @@ static_assert(RING == 2 || RING == 3, "one or two chunks of operands in flight")
 constexpr int conv_ops(int c) { return c == CR ? 2 : (c > CR && c < CR + NLD ? 3 : (c == CR + NLD ? 2 : 0)); }
 // operations issued behind chunk c's operand reads when the wave waits for them: the reads of the chunks requested
 // since (4 each) and the conversion steps of the chunks in between
+#ifndef SGP_SPLIT_SPREAD
+#define SGP_SPLIT_SPREAD 0
+#endif
+constexpr bool SPREAD = SGP_SPLIT_SPREAD != 0;   // the newest chunk's lo reads are issued behind the first MFMA instead of in front of the wait
 constexpr int lgkm_behind(int c, bool conv) {
     int n = 4 * ((c + RING - 1 < NCH ? c + RING - 1 : NCH - 1) - c);
+    if (SPREAD && c + RING - 1 < NCH) n -= 2;
     if (conv) for (int j = (c - (RING - 1) > 0 ? c - (RING - 1) : 0); j < c; ++j) n += conv_ops(j);
     return n;
 }
@@ -122,6 +127,13 @@ __device__ __forceinline__ void tr_issue(BOp& b, unsigned a0, unsigned a1) {
     asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %5\n\t"
                  "ds_read_b64_tr_b16 %2, %4 offset:256\n\tds_read_b64_tr_b16 %3, %5 offset:256"
                  : "=&v"(b.h0), "=&v"(b.h1), "=&v"(b.l0), "=&v"(b.l1) : "v"(a0), "v"(a1) : "memory");
+}
+// the same in two halves (hi pieces | lo pieces): -DSGP_SPLIT_SPREAD=1 puts an MFMA between them
+__device__ __forceinline__ void tr_issue_hi(BOp& b, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(b.h0), "=&v"(b.h1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void tr_issue_lo(BOp& b, unsigned a0, unsigned a1) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:256\n\tds_read_b64_tr_b16 %1, %3 offset:256" : "=&v"(b.l0), "=&v"(b.l1) : "v"(a0), "v"(a1) : "memory");
 }
 template <int N> __device__ __forceinline__ void tr_wait(BOp& b) {
     asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(b.h0), "+v"(b.h1), "+v"(b.l0), "+v"(b.l1) : "n"(N));
@@ -351,16 +363,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
         static_for<0, NCH>([&](auto C) {
             constexpr int c = decltype(C)::value;
             BOp& x = b[c % RING];
-            if constexpr (c + RING - 1 < NCH)
-                tr_issue(b[(c + RING - 1) % RING], addr_lo(cbo, ad[c + RING - 1]), addr_hi(cbo, ad[c + RING - 1]));
+            unsigned na0 = 0, na1 = 0;
+            if constexpr (c + RING - 1 < NCH) {
+                na0 = addr_lo(cbo, ad[c + RING - 1]); na1 = addr_hi(cbo, ad[c + RING - 1]);
+                if constexpr (SPREAD) tr_issue_hi(b[(c + RING - 1) % RING], na0, na1);
+                else tr_issue(b[(c + RING - 1) % RING], na0, na1);
+            }
             if (ABL(8)) tr_wait<lgkm_behind(c, false)>(x); else tr_wait<lgkm_behind(c, true)>(x);
             if (!ABL(2)) {
                 const h8 bh = cat8(x.h0, x.h1), bl = cat8(x.l0, x.l1);
                 // the cross terms go to a second accumulator so that consecutive MFMAs do not wait for each other
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][0], acc0, 0, 0, 0);
+                if constexpr (SPREAD && c + RING - 1 < NCH) tr_issue_lo(b[(c + RING - 1) % RING], na0, na1);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, af[c][0], acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc1, 0, 0, 0);
-            }
+            } else if constexpr (SPREAD && c + RING - 1 < NCH) tr_issue_lo(b[(c + RING - 1) % RING], na0, na1);
             if constexpr (c < NLD) { if (dma_now && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024)); }
             if constexpr (c >= CR && c <= CR + NLD) {
                 if (!ABL(8)) {

@@ -155,12 +155,16 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
                       f"{w['T']} steps, best of 3 per thread setting"}
 
 
-def RESERVOIR_ARITHMETIC(R, F):
-    """What sgp_reservoir_f32 computes with for this layer shape (include/sgp_amd.h; DESIGN.md 4.1 / 4.1a)."""
+def RESERVOIR_ARITHMETIC(R, F, N=None):
+    """What sgp_reservoir_f32 computes with for this layer shape (include/sgp_amd.h; DESIGN.md 4.1 / 4.1a / 4.1c)."""
     from sgp_amd import tune
-    if ((R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128))) and tune.get("res_bf3", 1, int) != 0:
-        return ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
-                "-- error vs fp64 equal to a CPU fp32 run's")
+    if tune.get("res_bf3", 1, int) == 0:
+        return "exact fp32 MFMA"
+    bf3 = ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
+           "-- error vs fp64 equal to a CPU fp32 run's")
+    small = N is not None and (N + 15) // 16 <= 512 and 32 < R <= 128 and F <= 32      # split-J form (reservoir_splitj_bf3.h)
+    if small or (R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128)):
+        return bf3
     return "exact fp32 MFMA"
 
 
@@ -485,7 +489,7 @@ def main():
             traffic, source = profiled_traffic(args.workload, kernel)
             if traffic is not None and pieces > 1:
                 traffic /= pieces                          # (profiled per launch of the same size)
-            res_arith = RESERVOIR_ARITHMETIC(R, F) if L == 1 else "exact fp32 MFMA"
+            res_arith = RESERVOIR_ARITHMETIC(R, F, N) if L == 1 else "exact fp32 MFMA"
             if kernel == "spmm_split":
                 rec["dtype"] = ("f32 (hop products: operands as fp16 hi + lo pairs, three 16-bit MFMA terms per "
                                 "product, fp32 accumulation -- agrees with fp32 to ~1e-7 of the operand scale; "

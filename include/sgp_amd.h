@@ -55,6 +55,10 @@ extern "C" {
 #define SGP_ACT_RELU      1
 #define SGP_ACT_SELF_NORM 2
 #define SGP_ACT_IDENTITY  3
+/* tanh evaluated with RELATIVE accuracy (an odd polynomial below |x| = 0.25; SGP_ACT_TANH is accurate to 3e-7 absolute,
+ * 6 instead of 14 instructions per value): for layers whose bias and input scaling are so small that their states are
+ * far below 1 -- sgp_amd's Python layer selects it when max |bias| < 0.25 */
+#define SGP_ACT_TANH_REL  4
 
 typedef void* sgp_stream_t;
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(64) void gesn_update_kernel(
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < NV; ++c) {
-        if (act == SGP_ACT_TANH) v[c] = tanhf(v[c]);
+        if (act == SGP_ACT_TANH || act == SGP_ACT_TANH_REL) v[c] = tanhf(v[c]);
         else if (act == SGP_ACT_RELU) v[c] = fmaxf(v[c], 0.f);
         ss = fmaf(v[c], v[c], ss);               // lanes beyond R hold 0
     }
@@ -220,7 +220,7 @@ int sgp_gesn_update_f32(const int32_t* rowptr, const int32_t* col, const float* 
                         int32_t n_nodes, int32_t R, sgp_stream_t stream) {
     SGP_REQUIRE(rowptr && col && val && z && p && h_in && h_out && out_row, "sgp_gesn_update_f32: null pointer");
     SGP_REQUIRE(n_nodes >= 0 && R > 0, "sgp_gesn_update_f32: bad size");
-    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_gesn_update_f32: unknown activation %d", act);
+    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_TANH_REL, "sgp_gesn_update_f32: unknown activation %d", act);
     if (R > 512) return sgp::fail(SGP_EUNSUP, "sgp_gesn_update_f32: reservoir size %d > 512 not supported", R);
     if (n_nodes == 0) return 0;
     return launch_update(rowptr, col, val, z, R, p, R, h_in, alpha, act, h_out, out_row, out_stride,
@@ -241,7 +241,7 @@ int sgp_gesn_f32(const int32_t* rowptr, const int32_t* col, const float* val,
                  int32_t T, int32_t N, int32_t F, int32_t R, int32_t L, sgp_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0 && L > 0, "sgp_gesn_f32: bad size");
-    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_gesn_f32: unknown activation %d", act);
+    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_TANH_REL, "sgp_gesn_f32: unknown activation %d", act);
     if (R > 512) return sgp::fail(SGP_EUNSUP, "sgp_gesn_f32: reservoir size %d > 512 not supported", R);
     if (T == 0 || N == 0) return 0;
     SGP_REQUIRE(rowptr && col && val && x && w_ih && w_hh && b && alpha && out && h_state && workspace,

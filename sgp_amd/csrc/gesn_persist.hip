@@ -70,7 +70,10 @@ __device__ __forceinline__ void ld4_agent(f32x4& r, const float* sbase, unsigned
 // < 3e-7): libdevice's tanhf is ~60 instructions per value, 16 values per lane and step -- it was a
 // third of the tick
 __device__ __forceinline__ float tanh_fast(float x) {
-    return fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f)), 1.f);
+    const float big = fmaf(-2.f, __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f)), 1.f);
+    const float x2 = x * x;                               // below 0.25 the odd polynomial keeps RELATIVE accuracy (reservoir_impl.h)
+    const float p = fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    return fabsf(x) < 0.25f ? x * p : big;
 }
 __device__ __forceinline__ void st4_agent(float* p, f32x4 v) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory");
@@ -342,7 +345,7 @@ __global__ __launch_bounds__(1024) void gesn_persistent(PArgs a) {
                 for (int s2 = 0; s2 < S; ++s2)
 #pragma unroll
                     for (int m = 0; m < 4; ++m) {
-                        if (a.act == SGP_ACT_TANH) v[s2][m] = tanh_fast(v[s2][m]);
+                        if (a.act == SGP_ACT_TANH || a.act == SGP_ACT_TANH_REL) v[s2][m] = tanh_fast(v[s2][m]);
                         else if (a.act == SGP_ACT_RELU) v[s2][m] = fmaxf(v[s2][m], 0.f);
                         ss = fmaf(v[s2][m], v[s2][m], ss);        // lanes beyond R hold 0
                     }

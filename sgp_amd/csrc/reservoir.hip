@@ -146,7 +146,7 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
                       sgp_stream_t stream) {
     SGP_REQUIRE(x && w_ih && w_hh && b && out && workspace, "sgp_reservoir_f32: null pointer");
     SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0, "sgp_reservoir_f32: bad size");
-    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_reservoir_f32: unknown activation %d", act);
+    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_TANH_REL, "sgp_reservoir_f32: unknown activation %d", act);
     SGP_REQUIRE(sgp::aligned16(workspace), "sgp_reservoir_f32: workspace must be 16-byte aligned");
     if (T == 0 || N == 0) return 0;
     const int jt = pick_jt(R), nkx = pick_nkx(F);

@@ -34,25 +34,38 @@ __host__ __device__ constexpr long long packed_floats(int JT, int NKX) {
     return (long long)JT * 16 + (long long)JT * NKX * 64 + (long long)JT * JT * 256;
 }
 
-// tanh(x) = 1 - 2 r(x), r(x) = 1 / (1 + e^{2x}): mul, v_exp_f32, add, v_rcp_f32 (two of them
-// quarter-rate) + one fma -- and the fma disappears into the leak,
+// tanh(x) = 1 - 2 r(x), r(x) = 1 / (1 + e^{2x}): mul, v_exp_f32, add, v_rcp_f32 (two of them quarter-rate) + one fma --
+// and the fma disappears into the leak,
 //     h' = (1-a) h + a tanh(x) = fma(-2a, r, fma(1-a, h, a)),
-// so activation + leak are 6 VALU instructions per value (8 with the sign-symmetric form used
-// before: |x|, copysign).  fp32 MFMAs do not co-execute with VALU work on gfx950 -- an instruction
-// in their shadow costs the SIMD ~10 cycles -- so every one saved is matrix-pipe time.  No branch,
-// no overflow case: e^{2x} -> inf gives r = 0, -> 0 gives r = 1.  Absolute error < 3e-7 everywhere
-// (tested); like the form before it, it trades the relative accuracy near zero that an
-// odd-polynomial branch would give (10 more instructions) -- the parity criterion is absolute.
+// so activation + leak are 6 VALU instructions per value.  No branch, no overflow case: e^{2x} -> inf gives r = 0, -> 0
+// gives r = 1.  ABSOLUTE error < 3e-7 everywhere (tested): fine for states of order 1 -- every reservoir whose bias is
+// the reference's U(-1, 1) -- but not for a reservoir whose bias AND input scaling are tiny (states of 1e-6 came out 6 %
+// off where the reference's tanh is relative-accurate; tests/test_gpu_split_contract.py found it).  Such layers are
+// run with SGP_ACT_TANH_REL (the Python layer picks it when max |bias| < 0.25):
+//   |x| >= 0.25: 1 - 2 / (1 + e^{2x})                                  (absolute 1.2e-7, i.e. relative <= 5e-7 there)
+//   |x| <  0.25: x (1 + x^2 (-1/3 + x^2 (2/15 - x^2 17/315)))          (next term 62/2835 x^8 <= 9e-8 relative)
+// 12 instructions + 2 for the leak -- measured +15 % on the large-N bf16-piece layer, +4-7 % on the split-J form, which
+// is why it is not the default form.
 __device__ __forceinline__ float tanh_r(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * 2.885390081777927f));
 }
 __device__ __forceinline__ float tanh_f32(float x) { return fmaf(-2.f, tanh_r(x), 1.f); }
-// leak with the activation value `v` (any activation), or with v = tanh_r(pre-activation)
-__device__ __forceinline__ float leak(float h, float v, float alpha, float one_minus_alpha) {
-    return one_minus_alpha * h + alpha * v;
-}
 __device__ __forceinline__ float leak_tanh_r(float h, float r, float alpha, float one_minus_alpha) {
     return fmaf(-2.f * alpha, r, fmaf(one_minus_alpha, h, alpha));
+}
+__device__ __forceinline__ float tanh_rel(float x) {
+    const float big = fmaf(-2.f, tanh_r(x), 1.f);
+    const float x2 = x * x;
+    const float p = fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    return fabsf(x) < 0.25f ? x * p : big;
+}
+// the element-wise activations that leave their VALUE in the accumulator (the plain leak follows): relu, tanh_rel
+__device__ __forceinline__ float act_value(float v, int act) {
+    return act == SGP_ACT_RELU ? fmaxf(v, 0.f) : tanh_rel(v);
+}
+// leak with the activation value `v` (any activation)
+__device__ __forceinline__ float leak(float h, float v, float alpha, float one_minus_alpha) {
+    return one_minus_alpha * h + alpha * v;
 }
 
 struct ResArgs {
@@ -211,11 +224,11 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-            } else if (a.act == SGP_ACT_RELU) {
+            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -441,11 +454,11 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
-            } else if (a.act == SGP_ACT_RELU) {
+            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = act_value(acc[i][jt][r], a.act);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -648,11 +661,11 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream8(ResArgs a) {
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
-            } else if (a.act == SGP_ACT_RELU) {
+            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = act_value(acc[i][jt][r], a.act);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -858,11 +871,11 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-            } else if (a.act == SGP_ACT_RELU) {
+            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -1092,11 +1105,11 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             for (int w = 0; w < JW; ++w)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[w][r] = tanh_r(acc[w][r]);
-        } else if (a.act == SGP_ACT_RELU) {
+        } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[w][r] = fmaxf(acc[w][r], 0.f);
+                for (int r = 0; r < 4; ++r) acc[w][r] = act_value(acc[w][r], a.act);
         }
         f32x4* hb = hbuf + (t & 1) * JT * 64;
         if (a.act == SGP_ACT_SELF_NORM) {

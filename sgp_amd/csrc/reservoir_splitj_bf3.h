@@ -210,11 +210,11 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
             for (int w = 0; w < JW; ++w)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pre[w][r] = tanh_r(pre[w][r]);
-        } else if (a.act == SGP_ACT_RELU) {
+        } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) pre[w][r] = fmaxf(pre[w][r], 0.f);
+                for (int r = 0; r < 4; ++r) pre[w][r] = act_value(pre[w][r], a.act);
         }
         if (a.act == SGP_ACT_SELF_NORM) {
             // norm over all R features: partial sums of the 4 waves meet in LDS

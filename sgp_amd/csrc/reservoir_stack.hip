@@ -364,11 +364,11 @@ __global__ __launch_bounds__(1024) void reservoir_stack(StackArgs a) {
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-            } else if (a.act == SGP_ACT_RELU) {
+            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -494,7 +494,7 @@ int sgp_reservoir_fused_sums_f32(const float* x, int64_t xrs, int64_t xss,
                                  sgp_stream_t stream) {
     SGP_REQUIRE(x && w_ih && w_hh && b && alpha && out && workspace, "sgp_reservoir_fused_f32: null pointer");
     SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0 && L >= 1, "sgp_reservoir_fused_f32: bad size");
-    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_IDENTITY, "sgp_reservoir_fused_f32: unknown activation %d", act);
+    SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_TANH_REL, "sgp_reservoir_fused_f32: unknown activation %d", act);
     SGP_REQUIRE(sgp::aligned16(workspace), "sgp_reservoir_fused_f32: workspace must be 16-byte aligned");
     for (int l = 0; l < L && l < kMaxLayers; ++l)
         SGP_REQUIRE(w_ih[l] && w_hh[l] && b[l], "sgp_reservoir_fused_f32: null weight pointer (layer %d)", l);

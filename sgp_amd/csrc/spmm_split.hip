@@ -82,6 +82,9 @@ static_assert(RING == 2 || RING == 3, "one or two chunks of operands in flight")
 constexpr int conv_ops(int c) { return c == CR ? 2 : (c > CR && c < CR + NLD ? 3 : (c == CR + NLD ? 2 : 0)); }
 // operations issued behind chunk c's operand reads when the wave waits for them: the reads of the chunks requested
 // since (4 each) and the conversion steps of the chunks in between
+#ifndef SGP_SPLIT_ACC3
+#define SGP_SPLIT_ACC3 0
+#endif
 #ifndef SGP_SPLIT_SPREAD
 #define SGP_SPLIT_SPREAD 0
 #endif
@@ -351,6 +354,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
         const unsigned cbo = lds0 + cur;
 
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#if SGP_SPLIT_ACC3
+        f32x4 acc2 = {0, 0, 0, 0};
+#endif
         f32x4 v, s4;
         BOp b[RING];
         stamp(u, 1);
@@ -376,7 +382,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][0], acc0, 0, 0, 0);
                 if constexpr (SPREAD && c + RING - 1 < NCH) tr_issue_lo(b[(c + RING - 1) % RING], na0, na1);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl, af[c][0], acc1, 0, 0, 0);
+#if SGP_SPLIT_ACC3
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc2, 0, 0, 0);
+#else
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc1, 0, 0, 0);
+#endif
             } else if constexpr (SPREAD && c + RING - 1 < NCH) tr_issue_lo(b[(c + RING - 1) % RING], na0, na1);
             if constexpr (c < NLD) { if (dma_now && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024)); }
             if constexpr (c >= CR && c <= CR + NLD) {
@@ -405,6 +415,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
             f32x4 iv;
             lds_read16(iv, tab_rs + sl * 64);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv));
+#if SGP_SPLIT_ACC3
+            acc1 += acc2;
+#endif
             const f32x4 r0 = (acc0 + acc1) * (iv * rinv);
             // an even slice waits for its odd neighbour: the two 64-byte halves of a 128-byte line leave together
             if (!(sl & 1) && sl + 1 < a.nslice && !ABL(32)) {

@@ -131,7 +131,8 @@ SIGNATURES = {
     "sgp_event_elapsed_ms": (ctypes.c_int, [c_p, c_p, ctypes.POINTER(c_f32)]),
 }
 
-ACT_CODES = {"tanh": 0, "relu": 1, "self_norm": 2, "identity": 3}
+ACT_CODES = {"tanh": 0, "relu": 1, "self_norm": 2, "identity": 3,
+             "tanh_rel": 4}     # tanh with relative accuracy near zero (layers whose bias is tiny: ReservoirLayer.kernel_activation)
 
 _lib = None
 

@@ -364,12 +364,25 @@ def test_reservoir_layer_single_step_and_tanh_accuracy():
     g = dict(w_ih=layer.w_ih.data, w_hh=layer.w_hh.data, b_ih=layer.b_ih.data, alpha=0.8)
     x, h = torch.randn(77, 6), torch.randn(77, 48)
     close(layer(x, h), O.reservoir_step(x, h, g, torch.tanh))
-    # tanh over the whole range through a 1x1 "reservoir": w_ih = 1, w_hh = 0, b = 0, alpha = 1
+    # tanh over the whole range through a 1x1 "reservoir": w_ih = 1, w_hh = 0, b = 0, alpha = 1.  The kernels' default
+    # form (bias of order 1) is accurate to 3e-7 ABSOLUTE; a layer whose bias is tiny -- like this one -- is run with the
+    # relative-accurate form (``ReservoirLayer.kernel_activation``), like the reference's own tanh
     one = sgp_amd.ReservoirLayer(1, 1, 0.9, 1.0)
     one.w_ih.data.fill_(1.); one.w_hh.data.zero_(); one.b_ih.data.zero_()
+    assert one.kernel_activation() == "tanh_rel"
     v = torch.cat([torch.linspace(-12, 12, 20001), torch.logspace(-8, 1, 2000)])
-    got = one(v[:, None], torch.zeros(v.numel(), 1))[:, 0]
-    assert float((got.double() - torch.tanh(v.double())).abs().max()) < 2.5e-7
+    w_ih, w_hh, b = one._device_weights(torch.device("cuda"))
+    for form in ("tanh", "tanh_rel"):
+        out = torch.empty(1, v.numel(), 1, device="cuda")
+        hip.reservoir_layer(v.cuda()[None, :, None], w_ih, w_hh, b, 1.0, form, out,
+                            torch.zeros(v.numel(), 1, device="cuda"))
+        assert float((out[0, :, 0].cpu().double() - torch.tanh(v.double())).abs().max()) < 2.5e-7, form
+    tiny = torch.cat([torch.logspace(-30, 0.5, 4000), -torch.logspace(-30, 0.5, 4000)])
+    got = one(tiny[:, None], torch.zeros(tiny.numel(), 1))[:, 0]
+    rel = ((got.double() - torch.tanh(tiny.double())) / torch.tanh(tiny.double())).abs()
+    assert float(rel.max()) < 6e-7, float(rel.max())
+    one.b_ih.data.fill_(0.7)
+    assert one.kernel_activation() == "tanh"
 
 
 # ------------------------------------------------------------------ encoders

@@ -200,12 +200,12 @@ int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride
  * (no host round trip, legal under stream capture).  flag = NULL clears it. */
 int sgp_launch_predicate(const int32_t* flag, int32_t run_if);
 
-/* Per-column statistics of a strided [batch, n_rows, feat] view over the steps 0, t_stride, 2 t_stride, ...:
- * stats[0 : feat] = max |x[:, c]| (bit pattern of the float; NaN / inf win), stats[feat : 2 feat] = sum of
- * squares.  accumulate = 0 clears stats first; 1 adds a second source (the halo rows of a node partition) to it.
- * feat % 4 == 0, feat <= 1024, 16-byte aligned rows. */
+/* Per-column statistics of a strided [batch, n_rows, feat] view over the steps 0, t_stride, 2 t_stride, ... and the rows
+ * 0, r_stride, 2 r_stride, ...: stats[0 : feat] = max |x[:, c]| (bit pattern of the float; NaN / inf win),
+ * stats[feat : 2 feat] = sum of squares.  accumulate = 0 clears stats first; 1 adds a second source (the halo rows of
+ * a node partition) to it.  feat % 4 == 0, feat <= 1024, 16-byte aligned rows. */
 int sgp_col_stats_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
-                      int32_t n_rows, int32_t batch, int32_t feat, int32_t t_stride, int32_t accumulate,
+                      int32_t n_rows, int32_t batch, int32_t feat, int32_t t_stride, int32_t r_stride, int32_t accumulate,
                       float* stats, sgp_stream_t stream);
 
 /* Scales, next bound and admission flag of the split-fp16 hop, on the device.  Per column c the bound B_c >= max

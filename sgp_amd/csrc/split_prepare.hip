@@ -20,6 +20,7 @@ namespace {
 // and sum of squares over the steps b = 0, t_stride, 2 t_stride, ...; feat % 4 == 0.
 __global__ __launch_bounds__(256) void col_stats_kernel(const float* x, long long xrs, long long xbs, int n_rows,
                                                         int t_stride, int feat, unsigned* amax, float* ssq) {
+    // (rows: the caller passes n_rows / r_stride and xrs * r_stride to read every r_stride-th row)
     const int q = feat >> 2;                                  // 16-byte pieces per row
     const int rpi = 256 / q;                                  // rows per pass of the block (q <= 256)
     const int r0 = threadIdx.x / q, c = threadIdx.x - r0 * q;
@@ -105,11 +106,13 @@ __global__ __launch_bounds__(256) void split_prepare_kernel(PrepArgs a) {
 extern "C" {
 
 int sgp_col_stats_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
-                      int32_t n_rows, int32_t batch, int32_t feat, int32_t t_stride, int32_t accumulate,
+                      int32_t n_rows, int32_t batch, int32_t feat, int32_t t_stride, int32_t r_stride, int32_t accumulate,
                       float* stats, sgp_stream_t stream) {
     SGP_REQUIRE(X && stats, "sgp_col_stats_f32: null pointer");
-    SGP_REQUIRE(n_rows >= 0 && batch >= 0 && feat > 0 && feat % 4 == 0 && feat <= 1024 && t_stride >= 1,
-                "sgp_col_stats_f32: feat must be a multiple of 4 up to 1024, t_stride >= 1");
+    SGP_REQUIRE(n_rows >= 0 && batch >= 0 && feat > 0 && feat % 4 == 0 && feat <= 1024 && t_stride >= 1 && r_stride >= 1,
+                "sgp_col_stats_f32: feat must be a multiple of 4 up to 1024, strides >= 1");
+    n_rows = (n_rows + r_stride - 1) / r_stride;              // rows 0, r_stride, 2 r_stride, ..
+    x_row_stride *= r_stride;
     SGP_REQUIRE(sgp::aligned16(X) && x_row_stride % 4 == 0 && x_batch_stride % 4 == 0, "sgp_col_stats_f32: rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
@@ -121,7 +124,8 @@ int sgp_col_stats_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stri
     SGP_REQUIRE(ns <= 65535, "sgp_col_stats_f32: more than 65535 sampled steps");
     const int rpi = 256 / (feat / 4);
     long long gx = ((long long)n_rows + rpi - 1) / rpi;
-    const long long cap = 2048 / ns > 0 ? 2048 / ns : 1;       // a couple of thousand workgroups, 16+ rows per thread where there are
+    const long long cap = 512 / ns > 0 ? 512 / ns : 1;         // ~two workgroups per CU: every one ends with 2 x feat atomics on the same
+                                                               // 2 x feat words (2048 workgroups spent 0.15 ms queueing on them)
     if (gx > cap) gx = cap;
     hipLaunchKernelGGL(col_stats_kernel, dim3((unsigned)gx, (unsigned)ns), dim3(256), 0, s,
                        X, (long long)x_row_stride, (long long)x_batch_stride, n_rows, t_stride, feat,

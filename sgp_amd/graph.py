@@ -326,6 +326,9 @@ class ShiftOperator:
             raise ValueError("halo batch / feature size differs from x")
         if force not in (None, "csr", "tiled", "res", "mix", "colblock", "split"):
             raise ValueError(f"unknown kernel {force!r} (csr, tiled, res, mix, colblock, split)")
+        if x.shape[0] == 0 or x.shape[2] == 0 or self.num_nodes == 0:
+            self.next_bound = self.last_split_flag = None
+            return y                                      # nothing to compute (an empty time chunk)
         plan = None if force in ("csr", "colblock", "split") else \
             self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,

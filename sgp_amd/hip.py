@@ -113,7 +113,7 @@ SIGNATURES = {
                                           c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
                                           c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p]),
     "sgp_launch_predicate": (ctypes.c_int, [c_p, c_i32]),
-    "sgp_col_stats_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
+    "sgp_col_stats_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     "sgp_split_prepare_f32": (ctypes.c_int, [c_p, c_f64, c_f64, c_i32, c_p, c_f32, c_f32, c_i32, c_p, c_p, c_p, c_p]),
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
@@ -352,20 +352,21 @@ def launch_predicate(flag, run_if):
 
 
 @_on_device
-def col_stats(x, t_stride=1, stats=None):
-    """Per-column max |x| (float bit patterns) and sum of squares of the steps 0, t_stride, .. of a [B, N, D] view,
-    as a device tensor ``[2, D]``; ``stats`` given = accumulate a second source into it."""
+def col_stats(x, t_stride=1, stats=None, r_stride=1):
+    """Per-column max |x| (float bit patterns) and sum of squares of the steps 0, t_stride, .. and rows 0, r_stride, .. of
+    a [B, N, D] view, as a device tensor ``[2, D]``; ``stats`` given = accumulate a second source into it."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
     acc = stats is not None
     if stats is None:
         stats = torch.empty(2, x.shape[2], dtype=torch.float32, device=x.device)
-    _check(lib.sgp_col_stats_f32(xp, xrs, xbs, x.shape[1], x.shape[0], x.shape[2], int(t_stride), int(acc),
+    _check(lib.sgp_col_stats_f32(xp, xrs, xbs, x.shape[1], x.shape[0], x.shape[2], int(t_stride), int(r_stride), int(acc),
                                  stats.data_ptr(), _stream(x)), "sgp_col_stats_f32")
     return stats
 
 
-SPLIT_SAMPLE_STEPS = 8         # steps the admission statistics of a hop read (all of them when there are fewer): 0.8 -> 0.2 GB on the target line
+SPLIT_SAMPLE_STEPS = 8         # steps the admission statistics of a hop read (all of them when there are fewer)
+SPLIT_SAMPLE_BYTES = 64 << 20  # ... and at most this many bytes of them (every r-th row beyond that): 0.8 GB -> 51 MB on the target line
 
 
 @_on_device
@@ -397,12 +398,14 @@ def split_profile(x, halo=None, bound=None, norm_inf=1.0, guard=True):
     if guard or measured:
         t_stride = 1 if measured else max(1, B // SPLIT_SAMPLE_STEPS)
         ns = -(-B // t_stride)
-        stats = col_stats(x, t_stride)
-        rows = N
+        r_stride = 1 if measured else max(1, -(-(ns * N * D * 4) // SPLIT_SAMPLE_BYTES))
+        stats = col_stats(x, t_stride, r_stride=r_stride)
+        rows, all_rows = -(-N // r_stride), N
         if halo is not None and halo.shape[1] > 0:
-            col_stats(halo, t_stride, stats)
-            rows += halo.shape[1]
-        n_samples, s_eff, full = float(ns) * rows, B / ns, int(t_stride == 1)
+            col_stats(halo, t_stride, stats, r_stride=r_stride)
+            rows += -(-halo.shape[1] // r_stride)
+            all_rows += halo.shape[1]
+        n_samples, s_eff, full = float(ns) * rows, (B * all_rows) / (float(ns) * rows), int(t_stride == 1 and r_stride == 1)
     _check(lib.sgp_split_prepare_f32(None if stats is None else stats.data_ptr(), n_samples, s_eff, full,
                                      None if b_in is None else b_in.data_ptr(), b_scalar, float(norm_inf), D,
                                      tab.data_ptr(), bound_out.data_ptr(), flag.data_ptr(), _stream(x)),

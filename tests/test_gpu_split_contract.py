@@ -164,6 +164,8 @@ def test_zero_columns_and_zero_operand(op):
     check_columns(y, *products(op, x))
     y, _ = default_hop(op, torch.zeros(2, N, D))
     assert float(y.abs().max()) == 0.0
+    empty = torch.empty(0, N, D, device="cuda")
+    assert op.propagate(empty, torch.empty_like(empty)).shape == (0, N, D)        # an empty time chunk is not an error
 
 
 def test_profile_kernels_against_numpy(op):
@@ -171,9 +173,9 @@ def test_profile_kernels_against_numpy(op):
     every bound in [2^13, 2^14], the next hop's bounds, the flag."""
     torch.manual_seed(6)
     x = (torch.randn(70, 500, 48) * torch.logspace(-3, 3, 48)).cuda()
-    for stride in (1, 2, 9):
-        st = hip.col_stats(x, stride).cpu()
-        xs = x.cpu()[::stride].flatten(0, 1)
+    for stride, rs in ((1, 1), (2, 1), (9, 3), (1, 7)):
+        st = hip.col_stats(x, stride, r_stride=rs).cpu()
+        xs = x.cpu()[::stride, ::rs].flatten(0, 1)
         assert torch.equal(st[0].view(torch.int32), xs.abs().max(0).values.view(torch.int32))
         assert torch.allclose(st[1], (xs.double() ** 2).sum(0).float(), rtol=1e-4)
     prof = hip.split_profile(x, None, None, norm_inf=2.5)

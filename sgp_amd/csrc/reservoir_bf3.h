@@ -252,11 +252,16 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
                     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-                } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+                } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                     for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
+                        for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+                } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_rel(acc[jt][r]);
                 } else if (a.act == SGP_ACT_SELF_NORM) {
                     float ss = 0.f;
 #pragma unroll

@@ -59,10 +59,6 @@ __device__ __forceinline__ float tanh_rel(float x) {
     const float p = fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
     return fabsf(x) < 0.25f ? x * p : big;
 }
-// the element-wise activations that leave their VALUE in the accumulator (the plain leak follows): relu, tanh_rel
-__device__ __forceinline__ float act_value(float v, int act) {
-    return act == SGP_ACT_RELU ? fmaxf(v, 0.f) : tanh_rel(v);
-}
 // leak with the activation value `v` (any activation)
 __device__ __forceinline__ float leak(float h, float v, float alpha, float one_minus_alpha) {
     return one_minus_alpha * h + alpha * v;
@@ -224,11 +220,16 @@ __global__ __launch_bounds__(JT <= 4 ? 1024 : 256, min_waves(JT, NT)) void reser
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+            } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+            } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_rel(acc[jt][r]);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -454,11 +455,16 @@ __global__ __launch_bounds__(256, 1) void reservoir_layer_stream(ResArgs a) {
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
-            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+            } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = act_value(acc[i][jt][r], a.act);
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+            } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_rel(acc[i][jt][r]);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -661,11 +667,16 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream8(ResArgs a) {
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
-            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+            } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = act_value(acc[i][jt][r], a.act);
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+            } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_rel(acc[i][jt][r]);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -871,11 +882,16 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-            } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+            } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[jt][r] = act_value(acc[jt][r], a.act);
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
+            } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_rel(acc[jt][r]);
             } else if (a.act == SGP_ACT_SELF_NORM) {
                 float ss = 0.f;
 #pragma unroll
@@ -1105,11 +1121,16 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj(ResArgs a) {
             for (int w = 0; w < JW; ++w)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[w][r] = tanh_r(acc[w][r]);
-        } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
+        } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
             for (int w = 0; w < JW; ++w)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[w][r] = act_value(acc[w][r], a.act);
+                for (int r = 0; r < 4; ++r) acc[w][r] = fmaxf(acc[w][r], 0.f);
+        } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[w][r] = tanh_rel(acc[w][r]);
         }
         f32x4* hb = hbuf + (t & 1) * JT * 64;
         if (a.act == SGP_ACT_SELF_NORM) {
@@ -1254,7 +1275,9 @@ int launch_splitj(const ResArgs& a, int n_tiles, hipStream_t s) {
     if constexpr (sjbf3_supported(JT, NKX) && sjbf3_lds_bytes(JT, NKX) <= kLdsLimit) {
         // three-piece bf16 products (reservoir_splitj_bf3.h): the step is no longer bound by the fp32 matrix pipe
         if (a.wp_bf3) {
-            auto kern = ov ? reservoir_layer_splitj_bf3<JT, NKX, true> : reservoir_layer_splitj_bf3<JT, NKX, false>;
+            void (*kern)(ResArgs);
+            if (a.act == SGP_ACT_TANH) kern = ov ? reservoir_layer_splitj_bf3<JT, NKX, true, SGP_ACT_TANH> : reservoir_layer_splitj_bf3<JT, NKX, false, SGP_ACT_TANH>;
+            else kern = ov ? reservoir_layer_splitj_bf3<JT, NKX, true, -1> : reservoir_layer_splitj_bf3<JT, NKX, false, -1>;
             const int bytes = (int)sjbf3_lds_bytes(JT, NKX);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -36,11 +36,19 @@ __host__ __device__ constexpr long long sjbf3_lds_bytes(int JT, int NKX) {
 #ifndef SGP_SJ_ABL
 #define SGP_SJ_ABL 0
 #endif
+#ifndef SGP_SJ_TILEWISE
+#define SGP_SJ_TILEWISE 1
+#endif
 constexpr bool sj_abl(int bit) { return (SGP_SJ_ABL & bit) != 0; }
 
-template <int JT, int NKX, bool OVEC>
+// ACT >= 0: the activation is known at compile time (the tanh instance carries no activation dispatch in its time loop:
+// the run-time form spent ~40 scalar branches per step on it), -1: read from the arguments
+template <int JT, int NKX, bool OVEC, int ACT>
 __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
     static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one input k-block");
+    const int act = ACT >= 0 ? ACT : a.act;
+    float alpha_v = a.alpha;              // a VGPR copy for the leak: hipcc 7.2 emitted v_fma_f32 with BOTH scalars (alpha, 1 - alpha)
+    asm("" : "+v"(alpha_v));              // as operands in this kernel ("violates constant bus restriction")
     constexpr int JW = JT / 4;                           // output tiles per wave
     constexpr int KBH = bf3_kbh(JT), KB = KBH + 1;       // recurrent k-blocks (two state tiles each) + the input block
     constexpr int PFD = sjbf3_ring(JT, NKX);
@@ -107,12 +115,14 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
     bool st_ok[JW];
 #pragma unroll
     for (int w = 0; w < JW; ++w) st_ok[w] = ok && 16 * (wave * JW + w) + 4 * q < a.R;
+    float* orow = a.out + (long long)node * a.ors + 16 * (wave * JW) + 4 * q;       // this lane's piece of step 0's row
     auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
+        float* ot = orow + (long long)t * a.oss;
 #pragma unroll
         for (int w = 0; w < JW; ++w) {
             const int j0 = 16 * (wave * JW + w) + 4 * q;
             if (st_ok[w]) {
-                float* op = a.out + (long long)t * a.oss + (long long)node * a.ors + j0;
+                float* op = ot + 16 * w;
                 if constexpr (OVEC) {
                     *reinterpret_cast<f32x4*>(op) = hv[w];
                 } else {
@@ -161,62 +171,115 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
         bf3_split8(xv, X[0], X[1], X[2]);
     };
     input_pieces(0);
+    // The input block does not depend on the state: its six products of step t + 1 are issued at the END of step t, behind
+    // the publication of the new state and in front of the barrier, where the wave would otherwise wait for its LDS writes
+    // and the other waves (two chains of three per tile: the second half's start does not wait for the first's result).
+    constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};         // W3 V1, W2 V2, W1 V3, W2 V1, W1 V2, W1 V1
+    f32x4 accx[JW][2];
+    auto input_block = [&]() {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int w = 0; w < JW; ++w) {
+                    const f32x4 c0 = h == 0 ? bias[w] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (!sj_abl(32)) accx[w][h] = bf3_mfma(W[w][KBH][PW[3 * h + i]], X[PV[3 * h + i]], i == 0 ? c0 : accx[w][h]);
+                    else if (i == 0) accx[w][h] = c0;
+                }
+    };
+    input_block();
 
     for (int t = 0; t < a.T; ++t) {
         if (t > 0 && !sj_abl(1)) store_h(t - 1, hown);
         if (wave == 0) dma_x(t + PFD - 1);               // into the slot consumed one step ago
-        // B operands: the state pieces of step t - 1 (all tiles); the input pieces were prepared during step t - 1
-        u32x4 V[KB][3];
+        // B operands: the state pieces of step t - 1 (all tiles), leading pieces of every k-block first (the first round
+        // of products needs exactly those)
+        u32x4 V[KBH][3];
         {
             const char* sp = slab + (size_t)((t & 1) ^ 1) * (3 * KBH * 1024) + lane * 16;
 #pragma unroll
-            for (int p = 0; p < KBH; ++p)
+            for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int p = 0; p < KBH; ++p)
                     V[p][pc] = *reinterpret_cast<const u32x4*>(sp + (pc * KBH + p) * 1024);
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) V[KBH][pc] = X[pc];
         }
-        // One accumulation chain per (output tile, k-block), added at the end; the six piece products (smallest first,
-        // reservoir_bf3.h) are the OUTER loop, so that consecutive MFMAs never wait for each other's result.  Measured
-        // (N = 325, R = 128 / N = 207, R = 64, us per step): this order 1.12 / 0.55; a k-block's six products back to back
-        // on one accumulator 1.41 / 0.66; tile by tile (5 chains at a time, the tail of tile 0 under the MFMAs of tile 1)
-        // 1.27 / 0.60; the six products of a k-block as two chains of three 1.23 / 0.65.
-        f32x4 acc[JW][KB];
-#pragma unroll
-        for (int w = 0; w < JW; ++w)
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb) acc[w][kb] = kb == KBH ? bias[w] : f32x4{0.f, 0.f, 0.f, 0.f};
-        constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};     // W3 V1, W2 V2, W1 V3, W2 V1, W1 V2, W1 V1
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-                for (int w = 0; w < JW; ++w)
-                    if (!sj_abl(32)) acc[w][kb] = bf3_mfma(W[w][kb][PW[i]], V[kb][PV[i]], acc[w][kb]);
-        // the input row of step t + 1 is visible since the last barrier (wave 0 retires rows two steps ahead): its pieces
-        // are cut here, in the shadow of the MFMAs
-        if (t + 1 < a.T) input_pieces(t + 1);
+        // One accumulation chain per (output tile, recurrent k-block), added at the end; the six piece products (smallest
+        // first, reservoir_bf3.h) are the OUTER loop, so that consecutive MFMAs never wait for each other's result.
+        // Measured (N = 325, R = 128 / N = 207, R = 64, us per step, with the input block still inside this loop): this
+        // order 1.12 / 0.55; a k-block's six products back to back on one accumulator 1.41 / 0.66 (a dependent MFMA issues
+        // ~29 cycles after the one it waits for, an independent one after 17); tile by tile (the tail of tile 0 under the
+        // MFMAs of tile 1) 1.27 / 0.60; the six products of a k-block as two chains of three 1.23 / 0.65.
+        // NCHN chains per tile, the k-blocks dealt to them in turn: a chain's next MFMA is NCHN x JW issues (>= 34 cycles) behind
+        // the one it waits for (29), and the end needs NCHN - 1 adds per tile instead of one per k-block -- with one chain
+        // per k-block the accumulators' zeroing, read-out (v_accvgpr) and adds were 100 of the step's 508 instructions.
+        constexpr int NCHN = JW == 1 ? (KBH < 3 ? KBH : 3) : 2;
         f32x4 pre[JW];
+        auto finish = [&](int w) {                       // leak, publish the pieces of tile w
+            f32x4 hn;
 #pragma unroll
-        for (int w = 0; w < JW; ++w) {
-            pre[w] = acc[w][KBH];
+            for (int r = 0; r < 4; ++r)
+                hn[r] = act == SGP_ACT_TANH ? leak_tanh_r(hown[w][r], pre[w][r], alpha_v, a.one_minus_alpha)
+                                            : leak(hown[w][r], pre[w][r], alpha_v, a.one_minus_alpha);
+            hown[w] = hn;
+            if (!sj_abl(16)) publish(t & 1, w, hn);
+        };
+        // Tile by tile (SGP_SJ_TILEWISE, JW = 2): the sum, activation, leak and piece cut of tile 0 sit in the program
+        // BEHIND the first products of tile 1, so that they issue in the gaps of tile 1's MFMAs instead of behind them.
+        constexpr bool TILEWISE = SGP_SJ_TILEWISE && JW == 2;
+        constexpr bool XEARLY = JW == 2;                  // (one tile per wave, R = 64: measured 0.51 against 0.48 us per step -- behind the publication there)
+        f32x4 xsum[JW];                                   // this step's input products (issued during the last step)
 #pragma unroll
-            for (int kb = 0; kb < KBH; ++kb) pre[w] += acc[w][kb];
+        for (int w = 0; w < JW; ++w) xsum[w] = accx[w][0] + accx[w][1];
+#pragma unroll
+        for (int w0 = 0; w0 < (TILEWISE ? JW : 1); ++w0) {
+            f32x4 acc[JW][NCHN];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int kb = 0; kb < KBH; ++kb)
+#pragma unroll
+                    for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        const bool first = i == 0 && kb < NCHN;        // (compile time: the loops are unrolled)
+                        if (!sj_abl(32))
+                            acc[w][kb % NCHN] = bf3_mfma(W[w][kb][PW[i]], V[kb][PV[i]], first ? zero : acc[w][kb % NCHN]);
+                        else if (first) acc[w][kb % NCHN] = zero;
+                    }
+            // the input row of step t + 1 is visible since the last barrier (wave 0 retires rows two steps ahead): its
+            // pieces are cut in the shadow of the MFMAs
+            if (w0 == 0 && t + 1 < a.T) input_pieces(t + 1);
+            // the input products of step t + 1 go out right behind the last recurrent products of this step: the tail of
+            // the last tile (sum, activation, leak, piece cut) then issues in THEIR gaps instead of in front of them
+            if (XEARLY && w0 == (TILEWISE ? JW : 1) - 1 && t + 1 < a.T) input_block();
+#pragma unroll
+            for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) {
+                pre[w] = xsum[w];
+#pragma unroll
+                for (int c = 0; c < NCHN; ++c) pre[w] += acc[w][c];
+            }
+            if (act == SGP_ACT_TANH && !sj_abl(8)) {
+#pragma unroll
+                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[w][r] = tanh_r(pre[w][r]);
+            } else if (act == SGP_ACT_RELU) {
+#pragma unroll
+                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[w][r] = fmaxf(pre[w][r], 0.f);
+            } else if (act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[w][r] = tanh_rel(pre[w][r]);
+            }
+            if (act != SGP_ACT_SELF_NORM) {
+#pragma unroll
+                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) finish(w);
+            }
         }
-        if (a.act == SGP_ACT_TANH && !sj_abl(8)) {
-#pragma unroll
-            for (int w = 0; w < JW; ++w)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pre[w][r] = tanh_r(pre[w][r]);
-        } else if (a.act == SGP_ACT_RELU || a.act == SGP_ACT_TANH_REL) {
-#pragma unroll
-            for (int w = 0; w < JW; ++w)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) pre[w][r] = act_value(pre[w][r], a.act);
-        }
-        if (a.act == SGP_ACT_SELF_NORM) {
+        if (act == SGP_ACT_SELF_NORM) {
             // norm over all R features: partial sums of the 4 waves meet in LDS
             float ss = 0.f;
 #pragma unroll
@@ -231,21 +294,13 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
             const float tot = red[n_in] + red[16 + n_in] + red[32 + n_in] + red[48 + n_in];
             const float inv = 1.f / fmaxf(sqrtf(tot), 1e-12f);
 #pragma unroll
-            for (int w = 0; w < JW; ++w)
+            for (int w = 0; w < JW; ++w) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pre[w][r] *= inv;
+                finish(w);
+            }
         }
-        // leak, publish the pieces of my tiles (the fp32 values are stored to HBM at the top of the next step)
-#pragma unroll
-        for (int w = 0; w < JW; ++w) {
-            f32x4 hn;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                hn[r] = a.act == SGP_ACT_TANH ? leak_tanh_r(hown[w][r], pre[w][r], a.alpha, a.one_minus_alpha)
-                                              : leak(hown[w][r], pre[w][r], a.alpha, a.one_minus_alpha);
-            hown[w] = hn;
-            if (!sj_abl(16)) publish(t & 1, w, hn);
-        }
+        if (!XEARLY && t + 1 < a.T) input_block();        // step t + 1's input products, in the shadow of the exchange
         // wave 0: the row of step t + 2 has landed once at most the (PFD - 3) NKX younger requests
         // (+ this step's stores, which only make the wait stricter) are outstanding
         if (wave == 0 && !sj_abl(4)) {

@@ -177,9 +177,15 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
     // part runs first), so they are in flight under the recurrent part, the activation and the stores of that tile
     f32x4 xr[NKX / 4];
     auto load_x = [&](int t, int i) {
-        const char* xp = reinterpret_cast<const char*>(a.x + (long long)t * a.xss);
+        // the step's base is opaque to the optimiser and stays a scalar: otherwise it folds xo[i] into a 64-bit pointer per
+        // lane and tile, which did not fit (one scratch reload and a vmcnt(0) per step in front of these loads)
+        unsigned long long xb = (unsigned long long)(a.x + (long long)t * a.xss);
+        asm volatile("" : "+s"(xb));
+        typedef const __attribute__((address_space(1))) char* gptr;
+        const gptr xp = (gptr)xb;
 #pragma unroll
-        for (int k4 = 0; k4 < NKX / 4; ++k4) xr[k4] = *reinterpret_cast<const f32x4*>(xp + xo[i] + 64 * k4);
+        for (int k4 = 0; k4 < NKX / 4; ++k4)
+            xr[k4] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(xp + xo[i] + 64 * k4);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the initial state has landed
     load_x(0, 0);

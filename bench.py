@@ -155,7 +155,7 @@ def cpu_baseline(w, ei, ew, seconds_budget=24.0):
                       f"{w['T']} steps, best of 3 per thread setting"}
 
 
-def RESERVOIR_ARITHMETIC(R, F, N=None):
+def RESERVOIR_ARITHMETIC(R, F, N=None, activation="tanh"):
     """What sgp_reservoir_f32 computes with for this layer shape (include/sgp_amd.h)."""
     from sgp_amd import tune
     if tune.get("res_bf3", 1, int) == 0:
@@ -163,7 +163,14 @@ def RESERVOIR_ARITHMETIC(R, F, N=None):
     bf3 = ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
            "-- error vs fp64 equal to a CPU fp32 run's")
     small = N is not None and (N + 15) // 16 <= 512 and 32 < R <= 128 and F <= 32      # split-J form (reservoir_splitj_bf3.h)
+    if small and activation == "tanh" and tune.get("res_h16", 1, int) != 0:
+        return ("recurrent products: state (|h| <= 1, x 2^14) and W_hh (per-row power-of-two scale) as two fp16 pieces "
+                "(22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; input products: three bf16 pieces; fp32 "
+                "accumulation -- error vs fp64 equal to a CPU fp32 run's")
     if small or (R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128)):
+        if R == 64 and not small and activation == "tanh":
+            bf3 += ("; the <= 512 node tiles the exact deal leaves over run the small-N form beside it (its recurrent "
+                    "products from two fp16 pieces, include/sgp_amd.h)")
         return bf3
     return "exact fp32 MFMA"
 

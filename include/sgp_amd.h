@@ -310,6 +310,15 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  * three bf16 pieces (24 bits, no scale, no bound on the values), six piece products per product on
  * v_mfma_f32_16x16x32_bf16, fp32 accumulation -- as close to the fp64 result as a CPU fp32 evaluation
  * (tests/test_gpu_reservoir_bf3.py); SGP_TUNE=res_bf3=0 keeps the fp32 matrix cores for them too.
+ * Small problems (<= 512 tiles of 16 nodes, 32 < R <= 128, F <= 32: csrc/reservoir_splitj_bf3.h) form the same
+ * three-piece products, except the RECURRENT ones under act = SGP_ACT_TANH: there the state lies in [-1, 1] (a convex
+ * combination of the old state and a tanh) and is cut into two fp16 pieces of 2^14 h, row j of w_hh into two fp16
+ * pieces under its own power-of-two scale (largest entry at 2^13 .. 2^14); hi hi + hi lo + lo hi on
+ * v_mfma_f32_16x16x32_f16, fp32 accumulation, the row sum scaled back exactly.  Per operand: relative 2^-23 down to
+ * 2^-16 of its bound (1 for the state, the row's largest |w|), absolute 2^-38 of the bound below -- far under the
+ * 3e-7 absolute accuracy of SGP_ACT_TANH itself.  A workgroup (16 nodes) whose INITIAL h_state has an entry outside
+ * [-1, 1] (or NaN) runs the three-piece loop instead, decided on the device; the other activations always do.
+ * SGP_TUNE=res_h16=0 keeps three bf16 pieces for the bounded state too.
  */
 int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R);
 int sgp_reservoir_f32(const float* x, int64_t x_row_stride, int64_t x_step_stride,

@@ -82,6 +82,42 @@ __global__ void pack_weights_bf3(const float* __restrict__ w_ih, const float* __
 }
 
 
+// Two-piece fp16 fragments of W_hh for the split-J kernel's bounded-state loop (reservoir_splitj_bf3.h): one thread per
+// (jt, kb, lane), row j scaled by the power of two that puts its largest entry at 2^13 .. 2^14 (computed here: a row is
+// at most 128 floats), 2^(-e_j - 14) -- the way back, the state's 2^14 included -- in front of the fragments.
+__global__ void pack_weights_sj16(const float* __restrict__ w_hh, char* __restrict__ out, int R, int JT) {
+    const int KBH = bf3_kbh(JT);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= JT * KBH * 64) return;
+    const int l = i & 63, kb = (i >> 6) % KBH, jt = (i >> 6) / KBH;
+    const int j = 16 * jt + (l & 15), g = l >> 4;
+    float amax = 0.f;
+    if (j < R)
+        for (int k = 0; k < R; ++k) amax = fmaxf(amax, fabsf(w_hh[(long long)j * R + k]));
+    int e = 0;
+    if (amax > 0.f && amax < __builtin_inff()) {
+        int k;
+        const float mant = frexpf(amax, &k);                   // amax = mant 2^k, mant in [0.5, 1)
+        e = (mant == 0.5f ? 15 : 14) - k;                       // floor(log2(16384 / amax))
+        e = min(100, max(-100, e));
+    }
+    const float ws = ldexpf(1.f, e);
+    if (kb == 0 && g == 0) reinterpret_cast<float*>(out)[j] = ldexpf(1.f, -e - 14);
+    unsigned hi[4], lo[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        float w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s = 2 * d + h, tt = 2 * kb + (s >> 2), k = 16 * tt + 4 * g + (s & 3);
+            w[h] = (j < R && tt < JT && k < R) ? w_hh[(long long)j * R + k] : 0.f;
+        }
+        sj16_split2(w[0], w[1], ws, hi[d], lo[d]);
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(out + (long long)JT * 64) + ((long long)(jt * KBH + kb) * 2) * 64 + l;
+    o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]}; o[64] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+}
+
 // streamed layout of the wide reservoirs: one thread per (sub-block = 2 k-block + half, tile of the half, lane)
 __global__ void pack_weights_sbf3(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
                                   const float* __restrict__ b, char* __restrict__ out, int F, int R, int JT, int NKX) {
@@ -134,6 +170,7 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     if (!jt || !nkx) return -1;
     // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
     return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
+           (sjbf3_supported(jt, nkx) ? sj16_packed_bytes(jt) : 0) +
            (sbf3_supported(jt, nkx) ? sbf3_packed_bytes(jt, nkx) + 1024 : 0);     // + dump area of the kernel
 }
 
@@ -164,6 +201,7 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     a.x = x; a.xrs = xrs; a.xss = xss;
     a.wp = (const float*)workspace;
     a.wp_bf3 = nullptr;
+    a.wp_h16 = nullptr;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
     // (the split-J form for small N -- R = 64 / 128, up to 32 input features -- takes any R <= 16 jt, F <= 4 nkx: padded
@@ -175,6 +213,16 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
         rc = sgp::check_launch("pack_weights_bf3");
         if (rc) return rc;
         a.wp_bf3 = wb;
+        // res_h16 = 0 (SGP_TUNE) keeps three bf16 pieces for the bounded (tanh) state of the split-J form too
+        static const bool use_h16 = sgp::tune("res_h16", 1) != 0;
+        if (use_h16 && sjbf3_supported(jt, nkx) && act == SGP_ACT_TANH) {
+            char* wh = wb + bf3_packed_bytes(jt, nkx);
+            const int th = jt * bf3_kbh(jt) * 64;
+            hipLaunchKernelGGL(pack_weights_sj16, dim3((th + 255) / 256), dim3(256), 0, s, w_hh, wh, R, jt);
+            rc = sgp::check_launch("pack_weights_sj16");
+            if (rc) return rc;
+            a.wp_h16 = wh;
+        }
     }
     if (use_bf3 && sbf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) {
         char* wb = (char*)workspace + bf3_offset(jt, nkx);

@@ -68,6 +68,7 @@ struct ResArgs {
     const float* x; long long xrs, xss;
     const float* wp;                 // packed weights (global workspace)
     const void* wp_bf3;              // the same weights as bf16 piece fragments (reservoir_bf3.h), or null
+    const void* wp_h16;              // W_hh as scaled two-piece fp16 fragments (reservoir_splitj_bf3.h), or null
     float* out; long long ors, oss;
     float* h_state;
     float alpha, one_minus_alpha;

@@ -23,7 +23,22 @@
 // Widths: R <= 16 JT, F <= 4 NKX with NKX <= 8 (one input k-block), any N, T; padded units / features carry zero
 // weights and zero operands, stores are masked like the fp32 kernel's.
 
+//
+// H16 (tanh, state within [-1, 1]): the RECURRENT products from TWO fp16 pieces per operand instead of three bf16 ones --
+// three products (lo hi, hi lo, hi hi) on v_mfma_f32_16x16x32_f16 instead of six, two pieces to cut, publish and read
+// instead of three (R = 128: 36 MFMAs per wave and step instead of 60).  The state is scaled by 2^14 (|h| <= 1: the
+// leak is a convex combination of the old state and a tanh), row j of W_hh by the power of two 2^e_j that puts its
+// largest entry at 2^13 .. 2^14 (pack_weights_sj16), the sum of a row is scaled back by 2^(-e_j - 14) -- all exact.
+// Error of one operand (spmm_split.hip's model): relative 2^-23 down to 2^-16 of the bound, absolute 2^-38 of the bound
+// below it (the low piece is an fp16 subnormal there); the dropped lo lo product is of order 2^-22.  The input block
+// keeps its three bf16 pieces (x is not bounded).  A workgroup whose INITIAL state leaves [-1, 1] (a caller's own
+// h_state) runs the three-piece loop instead: the choice is made per workgroup at the top of the kernel.
+
 __host__ __device__ constexpr bool sjbf3_supported(int JT, int NKX) { return (JT == 4 || JT == 8) && NKX <= 8; }
+// fp16 fragments of the recurrent blocks: [JT x 16 row scales 2^(-e_j - 14)] [JT][KBH][2 pieces][64 lanes][16 B]
+__host__ __device__ constexpr long long sj16_packed_bytes(int JT) { return JT * 64ll + (long long)JT * bf3_kbh(JT) * 2 * 1024; }
+__host__ __device__ constexpr int sj16_frag_off(int KBH, int jt, int kb, int pc) { return ((jt * KBH + kb) * 2 + pc) * 1024; }
+constexpr float kSj16StateScale = 16384.f;
 // LDS: piece slab [2][3][KBH][64][16 B] | self_norm partials [2][64] | input ring [PFD][NKX][64]
 __host__ __device__ constexpr long long sjbf3_slab_bytes(int JT) { return 2ll * 3 * bf3_kbh(JT) * 1024; }
 __host__ __device__ constexpr int sjbf3_ring(int JT, int NKX) { return 8; }
@@ -43,8 +58,22 @@ constexpr bool sj_abl(int bit) { return (SGP_SJ_ABL & bit) != 0; }
 
 // ACT >= 0: the activation is known at compile time (the tanh instance carries no activation dispatch in its time loop:
 // the run-time form spent ~40 scalar branches per step on it), -1: read from the arguments
-template <int JT, int NKX, bool OVEC, int ACT>
-__global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
+// two scaled fp16 pieces of a pair of values (v_fma_mixlo / mixhi_f16: fp32 fma rounded once to fp16 into one half of
+// the destination; the remainder of an 11-bit rounding of a 24-bit value is exact in the fma)
+__device__ __forceinline__ void sj16_split2(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
+    hi = 0; lo = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+__device__ __forceinline__ f32x4 sj16_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, v), acc, 0, 0, 0);
+}
+
+template <int JT, int NKX, bool OVEC, int ACT, bool H16>
+__device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one input k-block");
     const int act = ACT >= 0 ? ACT : a.act;
     float alpha_v = a.alpha;              // a VGPR copy for the leak: hipcc 7.2 emitted v_fma_f32 with BOTH scalars (alpha, 1 - alpha)
@@ -77,15 +106,25 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
         hown[w] = f32x4{hv[0], hv[1], hv[2], hv[3]};
     }
     // pieces of a tile's 4 values -> the slab of parity `par`
+    float hscale = kSj16StateScale;       // (a register: v_fma_mix takes no literal)
+    asm("" : "+v"(hscale));
     auto publish = [&](int par, int w, const f32x4 hv) {
         const int jt = wave * JW + w;
-        unsigned a1, a2, a3, b1, b2, b3;
-        bf3_split2(hv[0], hv[1], a1, a2, a3);
-        bf3_split2(hv[2], hv[3], b1, b2, b3);
         char* base = slab + (size_t)par * (3 * KBH * 1024) + (size_t)(jt >> 1) * 1024 + lane * 16 + (jt & 1) * 8;
-        *reinterpret_cast<uint2*>(base) = uint2{a1, b1};
-        *reinterpret_cast<uint2*>(base + KBH * 1024) = uint2{a2, b2};
-        *reinterpret_cast<uint2*>(base + 2 * KBH * 1024) = uint2{a3, b3};
+        if constexpr (H16) {
+            unsigned a1, a2, b1, b2;
+            sj16_split2(hv[0], hv[1], hscale, a1, a2);
+            sj16_split2(hv[2], hv[3], hscale, b1, b2);
+            *reinterpret_cast<uint2*>(base) = uint2{a1, b1};
+            *reinterpret_cast<uint2*>(base + KBH * 1024) = uint2{a2, b2};
+        } else {
+            unsigned a1, a2, a3, b1, b2, b3;
+            bf3_split2(hv[0], hv[1], a1, a2, a3);
+            bf3_split2(hv[2], hv[3], b1, b2, b3);
+            *reinterpret_cast<uint2*>(base) = uint2{a1, b1};
+            *reinterpret_cast<uint2*>(base + KBH * 1024) = uint2{a2, b2};
+            *reinterpret_cast<uint2*>(base + 2 * KBH * 1024) = uint2{a3, b3};
+        }
     };
 
     // input rows: lane (n, q) register ks <-> feature bf3_feature(NKX, q, ks), as pack_weights_bf3 orders the input block
@@ -135,18 +174,23 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
     };
     // this wave's weight fragments and bias: ONE wave per SIMD owns the whole register file, so the 3 KB x KB x 3 pieces
     // of its JW output tiles stay resident for all T steps (the fp32 form re-reads them from LDS every step)
-    u32x4 W[JW][KB][3];
-    f32x4 bias[JW];
+    constexpr int NP = H16 ? 2 : 3;                      // pieces per recurrent operand
+    u32x4 W[JW][KB][3];                                  // (H16: recurrent blocks [..][kb < KBH][0 .. 1] are fp16 fragments)
+    f32x4 bias[JW], rsc[JW];                             // rsc (H16): 2^(-e_j - 14) of this lane's 4 rows per tile
     {
         const char* wp = reinterpret_cast<const char*>(a.wp_bf3);
+        const char* wh = reinterpret_cast<const char*>(a.wp_h16);
 #pragma unroll
         for (int w = 0; w < JW; ++w) {
             bias[w] = *reinterpret_cast<const f32x4*>(wp + ((wave * JW + w) * 16 + q * 4) * 4);
+            if constexpr (H16) rsc[w] = *reinterpret_cast<const f32x4*>(wh + ((wave * JW + w) * 16 + q * 4) * 4);
 #pragma unroll
             for (int kb = 0; kb < KB; ++kb)
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    W[w][kb][pc] = *reinterpret_cast<const u32x4*>(wp + JT * 64 + bf3_frag_off(KB, wave * JW + w, kb, pc) + lane * 16);
+                for (int pc = 0; pc < (kb < KBH ? NP : 3); ++pc)
+                    W[w][kb][pc] = H16 && kb < KBH
+                        ? *reinterpret_cast<const u32x4*>(wh + JT * 64 + sj16_frag_off(KBH, wave * JW + w, kb, pc) + lane * 16)
+                        : *reinterpret_cast<const u32x4*>(wp + JT * 64 + bf3_frag_off(KB, wave * JW + w, kb, pc) + lane * 16);
         }
     }
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // vmcnt(0), visible to the compiler: state and weights have landed
@@ -175,6 +219,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
     // the publication of the new state and in front of the barrier, where the wave would otherwise wait for its LDS writes
     // and the other waves (two chains of three per tile: the second half's start does not wait for the first's result).
     constexpr int PW[6] = {2, 1, 0, 1, 0, 0}, PV[6] = {0, 1, 2, 0, 1, 0};         // W3 V1, W2 V2, W1 V3, W2 V1, W1 V2, W1 V1
+    constexpr int PW16[3] = {1, 0, 0}, PV16[3] = {0, 1, 0};                        // Wlo Vhi, Whi Vlo, Whi Vhi
     f32x4 accx[JW][2];
     auto input_block = [&]() {
 #pragma unroll
@@ -199,7 +244,7 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
         {
             const char* sp = slab + (size_t)((t & 1) ^ 1) * (3 * KBH * 1024) + lane * 16;
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                 for (int p = 0; p < KBH; ++p)
                     V[p][pc] = *reinterpret_cast<const u32x4*>(sp + (pc * KBH + p) * 1024);
@@ -235,16 +280,17 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
         for (int w0 = 0; w0 < (TILEWISE ? JW : 1); ++w0) {
             f32x4 acc[JW][NCHN];
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < (H16 ? 3 : 6); ++i)
 #pragma unroll
                 for (int kb = 0; kb < KBH; ++kb)
 #pragma unroll
                     for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) {
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                         const bool first = i == 0 && kb < NCHN;        // (compile time: the loops are unrolled)
-                        if (!sj_abl(32))
-                            acc[w][kb % NCHN] = bf3_mfma(W[w][kb][PW[i]], V[kb][PV[i]], first ? zero : acc[w][kb % NCHN]);
-                        else if (first) acc[w][kb % NCHN] = zero;
+                        const f32x4 c = first ? zero : acc[w][kb % NCHN];
+                        if (sj_abl(32)) { if (first) acc[w][kb % NCHN] = zero; }
+                        else if constexpr (H16) acc[w][kb % NCHN] = sj16_mfma(W[w][kb][PW16[i]], V[kb][PV16[i]], c);
+                        else acc[w][kb % NCHN] = bf3_mfma(W[w][kb][PW[i]], V[kb][PV[i]], c);
                     }
             // the input row of step t + 1 is visible since the last barrier (wave 0 retires rows two steps ahead): its
             // pieces are cut in the shadow of the MFMAs
@@ -254,9 +300,17 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
             if (XEARLY && w0 == (TILEWISE ? JW : 1) - 1 && t + 1 < a.T) input_block();
 #pragma unroll
             for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) {
-                pre[w] = xsum[w];
+                if constexpr (H16) {
+                    f32x4 rec = acc[w][0];
 #pragma unroll
-                for (int c = 0; c < NCHN; ++c) pre[w] += acc[w][c];
+                    for (int c = 1; c < NCHN; ++c) rec += acc[w][c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pre[w][r] = fmaf(rec[r], rsc[w][r], xsum[w][r]);
+                } else {
+                    pre[w] = xsum[w];
+#pragma unroll
+                    for (int c = 0; c < NCHN; ++c) pre[w] += acc[w][c];
+                }
             }
             if (act == SGP_ACT_TANH && !sj_abl(8)) {
 #pragma unroll
@@ -319,4 +373,22 @@ __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
                 if (ok && j0 + r < a.R) a.h_state[(long long)node * a.R + j0 + r] = hown[w][r];
         }
     }
+}
+
+template <int JT, int NKX, bool OVEC, int ACT>
+__global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
+    if constexpr (ACT == SGP_ACT_TANH) {
+        if (a.wp_h16) {
+            // the two-piece fp16 loop needs the state inside [-1, 1] at every step: true from step 1 on, checked here for
+            // the caller's initial state of this workgroup's 16 nodes (NaN fails the test too)
+            int out_of_range = 0;
+            if (a.h_state) {
+                const int node = blockIdx.x * 16 + (threadIdx.x & 15);
+                if (node < a.N)
+                    for (int j = threadIdx.x >> 4; j < a.R; j += 16) out_of_range |= !(fabsf(a.h_state[(long long)node * a.R + j]) <= 1.f);
+            }
+            if (!__syncthreads_or(out_of_range)) { splitj_bf3_body<JT, NKX, OVEC, ACT, true>(a); return; }
+        }
+    }
+    splitj_bf3_body<JT, NKX, OVEC, ACT, false>(a);
 }

@@ -148,3 +148,97 @@ def test_split_j_bf3_small_graphs(n, f, r, act, t):
     assert torch.equal(wide[:, :, 4:4 + r], out)                       # same bits whatever the cut, strided rows
     assert float(wide[:, :, :4].abs().max()) == 0.0 and float(wide[:, :, 4 + r:].abs().max()) == 0.0
     assert torch.equal(state[0], out[-1])
+
+
+def _per_unit_rel(got, ref):
+    """relative Frobenius error of every reservoir unit's series (the max-abs check of `check` says nothing about
+    units whose weights, and so whose states, are orders of magnitude below the others)"""
+    num = (got.double() - ref.double()).pow(2).sum(dim=(0, 1)).sqrt()
+    den = ref.double().pow(2).sum(dim=(0, 1)).sqrt()
+    return num / den.clamp_min(1e-300)
+
+
+@pytest.mark.parametrize("n,f,r", [(207, 3, 64), (325, 3, 128)])
+def test_split_j_two_piece_fp16_state_weight_rows_of_mixed_magnitude(n, f, r):
+    """The bounded-state loop of the split-J form (two fp16 pieces per recurrent operand, every row of W_hh under its own
+    power-of-two scale, reservoir_splitj_bf3.h): rows of W_hh seven orders of magnitude apart and entries five orders
+    apart INSIDE a row -- every unit's series is as close to fp64 as the CPU's fp32 run (relative, per unit)."""
+    hip.require_gpu()
+    torch.manual_seed(r)
+    res = sgp_amd.Reservoir(f, r, spectral_radius=0.9)
+    layer = res.reservoir_layers[0]
+    assert float(layer.b_ih.abs().max()) >= 0.25           # the kernel's activation code is tanh (not tanh_rel): the fp16 loop
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        rows = 10.0 ** (torch.rand(r, 1, generator=g) * 7 - 6)          # 1e-6 .. 10
+        inside = 10.0 ** (-5 * (torch.rand(r, r, generator=g) < 0.3).float() * torch.rand(r, r, generator=g))
+        layer.w_hh.data = (layer.w_hh.data * rows * inside).contiguous()
+        layer.w_hh.data *= 0.9 / float(torch.linalg.eigvals(layer.w_hh.data).abs().max())
+    t = 200
+    x = torch.randn(t, n, f)
+    out = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x.cuda(), out)
+    idx = torch.as_tensor(sorted({0, 1, 15, 16, n // 2, n - 2, n - 1}))
+    ref64 = O.reservoir_forward(x[:, idx], layers_of(res), dtype=torch.float64)
+    ref32 = O.reservoir_forward(x[:, idx], layers_of(res))
+    got = out[:, idx.cuda()].cpu()
+    e_gpu, e_cpu = _per_unit_rel(got, ref64), _per_unit_rel(ref32, ref64)
+    assert torch.isfinite(got).all()
+    # (the kernel's tanh is accurate to ~1e-7 absolute, sgp_amd.h: units whose state is tiny are held to that)
+    floor = 2e-7 / ref64.abs().amax(dim=(0, 1)).clamp_min(1e-30)
+    assert bool((e_gpu <= 4 * e_cpu + floor).all()), (float((e_gpu / (4 * e_cpu + floor)).max()), int((e_gpu / (4 * e_cpu + floor)).argmax()))
+    assert float(e_gpu.max()) <= 1e-5
+
+
+def test_split_j_two_piece_fp16_state_leaves_to_the_three_piece_loop_outside_the_unit_interval():
+    """A caller's initial state outside [-1, 1] (the fp16 pieces are scaled for |h| <= 1): the workgroups holding such
+    nodes run the three-piece bf16 loop (decided in the kernel, per workgroup), the others the fp16 loop -- both as
+    close to fp64 as the CPU; a NaN in the initial state stays with its node."""
+    hip.require_gpu()
+    torch.manual_seed(9)
+    n, f, r, t = 325, 3, 128, 80
+    res = sgp_amd.Reservoir(f, r, spectral_radius=0.9, leaking_rate=0.7)
+    x = torch.randn(t, n, f)
+    h0 = torch.rand(1, n, r) * 2 - 1
+    h0[0, 40] *= 50.0                                       # node tile 2
+    h0[0, 300, 7] = -3.0                                    # node tile 18
+    h0[0, 17, 5] = 1.0                                      # exactly on the bound: stays with the fp16 loop
+    state = h0.clone().cuda()
+    out = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x.cuda(), out, state)
+    idx = torch.as_tensor([0, 17, 32, 40, 47, 48, 299, 300, 324])
+    ref64 = O.reservoir_forward(x[:, idx], layers_of(res), h0=h0[:, idx], dtype=torch.float64)
+    ref32 = O.reservoir_forward(x[:, idx], layers_of(res), h0=h0[:, idx])
+    got = out[:, idx.cuda()].cpu()
+    e_gpu = float((got.double() - ref64).abs().max())
+    e_cpu = float((ref32.double() - ref64).abs().max())
+    assert e_gpu <= 2 * e_cpu + 1e-6, (e_gpu, e_cpu)
+    assert torch.equal(state[0], out[-1])
+    h0[0, 100, 3] = float("nan")
+    state = h0.clone().cuda()
+    res.encode_into(x.cuda(), out, state)
+    assert bool(torch.isnan(out[:, 100]).any()) and bool(torch.isfinite(out[:, :100]).all()) and bool(torch.isfinite(out[:, 101:]).all())
+
+
+def test_split_j_two_piece_fp16_loop_is_the_one_that_runs():
+    """SGP_TUNE=res_h16=0 (three bf16 pieces for the bounded state too) gives different low bits than the default: the
+    fp16 loop is not silently skipped; both stay within the CPU fp32 run's distance from fp64."""
+    import os
+    import subprocess
+    import sys
+    hip.require_gpu()
+    code = ("import torch, sgp_amd, hashlib, sys\n"
+            "torch.manual_seed(4)\n"
+            "res = sgp_amd.Reservoir(3, 128, spectral_radius=0.9)\n"
+            "x = torch.randn(64, 325, 3)\n"
+            "out = torch.empty(64, 325, 128, device='cuda')\n"
+            "res.encode_into(x.cuda(), out)\n"
+            "print('HASH', hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest())\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = []
+    for tune in ("res_h16=0", "res_h16=1"):
+        env = dict(os.environ, SGP_TUNE=tune, PYTHONPATH=root)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        hashes.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][0])
+    assert hashes[0] != hashes[1]

@@ -23,7 +23,7 @@ def child():
     import oracle.sgp_oracle as O
     g = [dict(w_ih=l.w_ih.data.cpu(), w_hh=l.w_hh.data.cpu(), b_ih=l.b_ih.data.cpu(), alpha=float(l.alpha))
          for l in res.reservoir_layers]
-    tt = min(t, 64)
+    tt = min(t, int(os.environ.get("PROBE_TT", "64")))
     ref = O.reservoir_forward(x[:tt, :64].cpu(), g, "tanh", dtype=torch.float64)
     err = float((out[:tt, :64].cpu().double() - ref).abs().max())
     ref32 = O.reservoir_forward(x[:tt, :64].cpu(), g, "tanh")

@@ -180,6 +180,45 @@ def require_gpu():
     return lib
 
 
+_masked_streams = {}
+
+
+def cu_masked_streams(device, n_reserved):
+    """Two HIP streams that split the device's compute units: ``(few, rest)`` -- ``few`` may run on ``n_reserved`` CUs only,
+    ``rest`` on all the others (hipExtStreamCreateWithCUMask; mask bit i is CU i of the runtime's numbering, which
+    interleaves the XCDs: a multiple of 8 reserves the same number in every XCD).  For a latency-bound kernel of a
+    few workgroups (the small-graph reservoir: one wave per SIMD) that runs BESIDE bandwidth-bound kernels filling the
+    chip: without the split the dispatcher puts waves of both on the same SIMDs and the serial chain pays for every
+    issue slot it loses.  Returns None when the runtime refuses (the caller keeps ordinary streams)."""
+    dev = torch.device(device)
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), int(n_reserved))
+    if key in _masked_streams:
+        return _masked_streams[key]
+    pair = None
+    if 0 < n_reserved < total:
+        try:
+            rt = ctypes.CDLL("libamdhip64.so")
+            words = (total + 31) // 32
+            made = []
+            for bits in (range(0, n_reserved), range(n_reserved, total)):
+                mask = (ctypes.c_uint32 * words)()
+                for b in bits:
+                    mask[b // 32] |= 1 << (b % 32)
+                h = ctypes.c_void_p()
+                with torch.cuda.device(dev):
+                    rc = rt.hipExtStreamCreateWithCUMask(ctypes.byref(h), ctypes.c_uint32(words), mask)
+                if rc != 0 or not h.value:
+                    made = None
+                    break
+                made.append(torch.cuda.ExternalStream(h.value, device=dev))
+            pair = tuple(made) if made else None
+        except (OSError, AttributeError):
+            pair = None
+    _masked_streams[key] = pair
+    return pair
+
+
 def _check(rc, what):
     if rc != 0:
         msg = load().sgp_last_error().decode()

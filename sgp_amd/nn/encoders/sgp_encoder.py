@@ -1,7 +1,7 @@
 import torch
 from torch import nn
 
-from ... import hip
+from ... import hip, tune
 from ..reservoir import Reservoir
 from ._args import add_reservoir_args, add_spatial_args
 from .sgp_spatial_encoder import SGPSpatialEncoder
@@ -131,18 +131,21 @@ class SGPEncoder(nn.Module):
     # the hops are worth it (their estimated time >= a quarter of the chain's), the time axis is cut
     # into `overlap_chunks` pieces and the hops (+ global mean) of piece i run on a second stream under
     # the reservoir of piece i + 1 (state carried on the device: bit-identical to one pass).
-    # PEMS-BAY shape: 107 -> 93 ms per pass (the chain runs ~10 % slower beside the hops); METR-LA
-    # shape (K = 2, hops = 7 % of the pass) keeps one piece: cut in 8 it took 30 ms instead of 22.
+    # PEMS-BAY shape: 107 -> 93 ms per pass in round 2 (the chain runs ~13 % slower beside the hops -- the clock under
+    # load, not its neighbours: its own compute units and no row wait changed nothing); METR-LA shape (K = 2, hops = 7 %
+    # of the pass) keeps one piece: cut in 8 it took 30 ms instead of 22.  Round 5 (chain 0.76 us per step, hops 33 of
+    # the 39 ms beside it): 8 pieces 49.0 ms, 12: 45.2, 16: 45.0, 24: 48.3 -- the tail is the last piece's hops.
     overlap_tiles = 128
-    overlap_chunks = 8
+    overlap_chunks = 16
+    overlap_masked_tiles = 32      # the chain gets its own compute units up to this many node tiles (hip.cu_masked_streams)
 
     def _overlap_pieces(self, T, N):
-        if (N + 15) // 16 > self.overlap_tiles or T < 64 * self.overlap_chunks:
+        if (N + 15) // 16 > self.overlap_tiles or T < 64 * tune.get("overlap_chunks", self.overlap_chunks, int):
             return 1
         L, R = len(self.reservoir.reservoir_layers), self.reservoir.hidden_size
-        chain_us = (0.3 + 7.3e-5 * R * R) * L                 # per step: 0.6 us at R = 64, 1.5 at 128 (measured)
+        chain_us = (0.27 + 3.0e-5 * R * R) * L                # per step: 0.39 us at R = 64, 0.76 at 128 (measured)
         hop_us = (self.sgp_encoder.num_blocks() - 1) * N * L * R * 8 / 4e6   # bytes of the hop blocks at ~4 TB/s
-        return self.overlap_chunks if hop_us >= 0.25 * chain_us else 1
+        return tune.get("overlap_chunks", self.overlap_chunks, int) if hop_us >= 0.25 * chain_us else 1
 
     def _state_bound(self, state=None):
         """Upper bound of |reservoir state| where one holds: a leaky average ``(1 - a) h + a act(.)`` of values in
@@ -187,14 +190,25 @@ class SGPEncoder(nn.Module):
         key = str(x.device)
         if key not in self._side_streams:
             self._side_streams[key] = torch.cuda.Stream(device=x.device)
-        side = self._side_streams[key]
+        side, chain = self._side_streams[key], main
+        # The chain (one wave per SIMD on ceil(N / 16) CUs) and the hops (every CU) on DISJOINT compute units: the small
+        # kernels between two pieces of the chain (weight packing) no longer queue behind hop workgroups (65 -> 5 us
+        # each; PEMS-BAY shape 51.2 -> 48.6 ms per pass).  Up to 32 tiles.
+        tiles = (N + 15) // 16
+        if tiles <= self.overlap_masked_tiles and tune.get("overlap_cu_mask", 1, int):
+            pair = hip.cu_masked_streams(x.device, (tiles + 7) // 8 * 8)
+            if pair is not None:
+                chain, side = pair
         side.wait_stream(main)                                  # (out / earlier work of the caller)
+        if chain is not main:
+            chain.wait_stream(main)
         for j in range(chunks):
             t0, t1 = T * j // chunks, T * (j + 1) // chunks
-            sums = torch.empty(t1 - t0, d_h, dtype=torch.float32, device=x.device) if want_sums else None
-            self.reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state, col_sums=sums)
-            ready = torch.cuda.Event()
-            ready.record(main)
+            with torch.cuda.stream(chain):
+                sums = torch.empty(t1 - t0, d_h, dtype=torch.float32, device=x.device) if want_sums else None
+                self.reservoir.encode_into(x[t0:t1], out[t0:t1, :, :d_h], state, col_sums=sums)
+                ready = torch.cuda.Event()
+                ready.record(chain)
             with torch.cuda.stream(side):
                 side.wait_event(ready)
                 self.sgp_encoder.encode_into(out[t0:t1], d_h, ops, timeline, col_sums=sums,
@@ -202,6 +216,8 @@ class SGPEncoder(nn.Module):
                 if sums is not None:
                     sums.record_stream(side)
         main.wait_stream(side)
+        if chain is not main:
+            main.wait_stream(chain)
         return out
 
     # Device-memory budget for one pass (bytes); None = 80 % of what is free right now.  Host

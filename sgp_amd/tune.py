@@ -10,6 +10,8 @@ Python layer
     mix_min_share=0.25      least share of (group, column) pairs in the dense part for the mixed kernel to be chosen
     colblock=1|0            column-blocked hop for graphs without locality (0: generic CSR kernel)
     colblock_l2_mb=2.5      L2 budget of one column block
+    overlap_chunks=16       small graphs: time pieces of the reservoir-over-hops pipeline (SGPEncoder.encode_device)
+    overlap_cu_mask=1|0     small graphs: the reservoir chain and the hops beside it run on disjoint compute units (0: ordinary streams)
     equal_cost_tiles=0|1, equal_cost_q=0.15   experiment: tiles cut for equal cost
 
 Library (integers)

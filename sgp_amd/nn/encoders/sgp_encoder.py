@@ -128,24 +128,28 @@ class SGPEncoder(nn.Module):
 
     # Small graphs: the reservoir is a serial chain of T steps on ceil(N / 16) CUs (PEMS-BAY: 21 of
     # 256) and the hops are bandwidth-bound on all of them.  Up to `overlap_tiles` node tiles, and when
-    # the hops are worth it (their estimated time >= a quarter of the chain's), the time axis is cut
-    # into `overlap_chunks` pieces and the hops (+ global mean) of piece i run on a second stream under
+    # the hops are worth it (their estimated time >= a tenth of the chain's), the time axis is cut
+    # into up to `overlap_chunks` pieces and the hops (+ global mean) of piece i run on a second stream under
     # the reservoir of piece i + 1 (state carried on the device: bit-identical to one pass).
     # PEMS-BAY shape: 107 -> 93 ms per pass in round 2 (the chain runs ~13 % slower beside the hops -- the clock under
-    # load, not its neighbours: its own compute units and no row wait changed nothing); METR-LA shape (K = 2, hops = 7 %
-    # of the pass) keeps one piece: cut in 8 it took 30 ms instead of 22.  Round 5 (chain 0.76 us per step, hops 33 of
-    # the 39 ms beside it): 8 pieces 49.0 ms, 12: 45.2, 16: 45.0, 24: 48.3 -- the tail is the last piece's hops.
+    # load, not its neighbours: its own compute units and no row wait changed nothing).
+    # Round 5 (chain 0.76 us per step, hops 33 of the 39 ms beside it): 8 pieces 49.0 ms, 12: 45.2, 16: 45.0, 24: 48.3 -- the tail is the last piece's hops.
     overlap_tiles = 128
     overlap_chunks = 16
     overlap_masked_tiles = 32      # the chain gets its own compute units up to this many node tiles (hip.cu_masked_streams)
 
     def _overlap_pieces(self, T, N):
-        if (N + 15) // 16 > self.overlap_tiles or T < 64 * tune.get("overlap_chunks", self.overlap_chunks, int):
+        if (N + 15) // 16 > self.overlap_tiles:
             return 1
         L, R = len(self.reservoir.reservoir_layers), self.reservoir.hidden_size
         chain_us = (0.27 + 3.0e-5 * R * R) * L                # per step: 0.39 us at R = 64, 0.76 at 128 (measured)
         hop_us = (self.sgp_encoder.num_blocks() - 1) * N * L * R * 8 / 4e6   # bytes of the hop blocks at ~4 TB/s
-        return tune.get("overlap_chunks", self.overlap_chunks, int) if hop_us >= 0.25 * chain_us else 1
+        share = hop_us / chain_us
+        # hops as long as the chain (PEMS-BAY shape, 0.9): 16 pieces; a tenth of it (METR-LA shape, 0.14): 4 pieces take
+        # 14.2 ms against 14.8 in one piece, 14.5 in 8 and 15.0 in 16 -- every piece costs a launch gap of the chain
+        pieces = self.overlap_chunks if share >= 0.5 else 8 if share >= 0.25 else 4 if share >= 0.1 else 1
+        pieces = tune.get("overlap_chunks", pieces, int)
+        return pieces if T >= 64 * pieces else 1
 
     def _state_bound(self, state=None):
         """Upper bound of |reservoir state| where one holds: a leaky average ``(1 - a) h + a act(.)`` of values in

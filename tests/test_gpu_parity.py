@@ -1136,7 +1136,7 @@ def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical():
                              bidirectional=True, alpha_decay=False, global_attr=True)
     ops = enc.sgp_encoder.operators(n, ei, ew)
     x = torch.randn(t, n, 3).cuda()
-    assert enc._overlap_pieces(t, n) == 8 and enc._overlap_pieces(t, 100000) == 1
+    assert enc._overlap_pieces(t, n) == 16 and enc._overlap_pieces(t, 100000) == 1 and enc._overlap_pieces(1000, n) == 1
     out = enc.encode_device(x, ops)
     again = enc.encode_device(x, ops)
     enc.overlap_chunks = 1
@@ -1149,11 +1149,26 @@ def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical():
     a = enc.encode_device(x[:600], ops, state=st)
     b = enc.encode_device(x[600:], ops, state=st)
     assert torch.equal(torch.cat([a, b]), plain)
-    # METR-LA-like settings (K = 2, one direction): hops too small to be worth the pieces
+    # METR-LA-like settings (K = 2, one direction): hops a seventh of the chain -- four pieces
     enc2 = sgp_amd.SGPEncoder(input_size=3, reservoir_size=64, reservoir_layers=1, leaking_rate=.9,
                               spectral_radius=.9, density=.7, input_scaling=1., receptive_field=2,
                               bidirectional=False, alpha_decay=False, global_attr=False)
-    assert enc2._overlap_pieces(34272, 207) == 1
+    assert enc2._overlap_pieces(34272, 207) == 4
+    x2 = torch.randn(700, 207, 3).cuda()
+    ei2, ew2 = synthetic.sparse_traffic_graph(207, 1515, seed=3)
+    ops2 = enc2.sgp_encoder.operators(207, ei2, ew2)
+    cut = enc2.encode_device(x2, ops2)
+    import os
+    saved = os.environ.get("SGP_TUNE")
+    os.environ["SGP_TUNE"] = "overlap_chunks=1" + ("," + saved if saved else "")
+    try:
+        whole = enc2.encode_device(x2, ops2)
+    finally:
+        if saved is None:
+            del os.environ["SGP_TUNE"]
+        else:
+            os.environ["SGP_TUNE"] = saved
+    assert torch.equal(cut, whole)
 
 
 def test_spatial_supports_propagate_on_gpu():

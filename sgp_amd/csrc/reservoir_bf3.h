@@ -127,8 +127,14 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 
 // of them -- an exec-masked store, a wave-uniform `tile exists` test -- it falls back to vmcnt(0) at the top of every
 // tile and step, and the step waits for its own stores to reach memory (measured: 5360 cycles per tile and step).
 // N is a multiple of 16 here: the nodes of a ragged last tile go to the exact-fp32 kernel (launch_layer).
-template <int JT, int NKX, int NT>
-__global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
+// PAIR (NT = 2, at most three waves per SIMD: 170 registers, 162-168 used): a wave multiplies its two tiles TOGETHER --
+// every weight fragment read from the LDS serves both (24 instead of 48 KB of LDS reads per tile and step), four
+// accumulators take turns behind every pair of fragments.  Measured N = 100 000, 256 steps: 3.46 -> 3.36 ms.  (The
+// `-DSGP_BF3_ABL=32` build without any fragment read runs at 2.75 ms, but on undefined operands: NaNs through the matrix
+// pipe draw less power and the clock rises -- the LDS is 28 % busy here, not the limit.)
+template <int JT, int NKX, int NT, bool PAIR = false>
+__global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_layer_bf3(ResArgs a) {
+    static_assert(!PAIR || NT == 2, "the pair loop is written for two tiles per wave");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KBH = bf3_kbh(JT), KBX = bf3_kbx(NKX), KB = KBH + KBX, NP = JT / 2, NU = KB * NP;
     {
@@ -175,7 +181,7 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
     // the input rows of ONE tile and step (register 4 k4 + s <-> feature 16 k4 + 4 q + s: the four lanes of a node read
     // 64 consecutive bytes per instruction): requested right after the rows before them were consumed (the input
     // part runs first), so they are in flight under the recurrent part, the activation and the stores of that tile
-    f32x4 xr[NKX / 4];
+    f32x4 xr[PAIR ? 2 : 1][NKX / 4];
     auto load_x = [&](int t, int i) {
         // the step's base is opaque to the optimiser and stays a scalar: otherwise it folds xo[i] into a 64-bit pointer per
         // lane and tile, which did not fit (one scratch reload and a vmcnt(0) per step in front of these loads)
@@ -185,10 +191,11 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
         const gptr xp = (gptr)xb;
 #pragma unroll
         for (int k4 = 0; k4 < NKX / 4; ++k4)
-            xr[k4] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(xp + xo[i] + 64 * k4);
+            xr[PAIR ? i : 0][k4] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(xp + xo[i] + 64 * k4);
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the initial state has landed
     load_x(0, 0);
+    if constexpr (PAIR) load_x(0, my_nt > 1 ? 1 : 0);
     const unsigned fa = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + JT * 16) + lane * 16;
 
 
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
                         if constexpr (kb >= KBH) {
                             constexpr int p = kb - KBH;
 #pragma unroll
-                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
+                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[0][(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
                         } else {
 #pragma unroll
                             for (int s = 0; s < 8; ++s) v[s] = h[i][2 * kb + (s >> 2)][s & 3];
@@ -296,7 +303,108 @@ __global__ __launch_bounds__(1024, 4) void reservoir_layer_bf3(ResArgs a) {
             }
         }
     };
-    if (NT > 1 && my_nt > 1) run(Bf3C<NT>{}); else run(Bf3C<1>{});
+    // two tiles in lockstep: the unit loop of `run` with every fragment multiplied against both tiles' pieces
+    auto run_pair = [&]() {
+        for (int t = 0; t < a.T; ++t) {
+            int wo = 0;
+            asm volatile("" : "+v"(wo));
+            const float* bias_t = lds + wo;
+            f32x4 acc[2][JT];
+#pragma unroll
+            for (int jt = 0; jt < JT; ++jt) acc[0][jt] = acc[1][jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+            u32x4 ring[6];
+            bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 2)>(ring[1], fa);
+            bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 1)>(ring[3], fa);
+            u32x4 v1[2], v2[2], v3[2];
+            bf3_for<0, NU>([&](auto uc) {
+                constexpr int u = decltype(uc)::value, kb = bf3_unit_kb(JT, NKX, u), j0 = 2 * (u % NP), j1 = j0 + 1;
+                constexpr bool last = u + 1 == NU;
+                constexpr int un = last ? 0 : u + 1, kbn = bf3_unit_kb(JT, NKX, un), n0 = 2 * (un % NP), n1 = n0 + 1;
+                if constexpr (u % NP == 0) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float v[8];
+                        if constexpr (kb >= KBH) {
+                            constexpr int p = kb - KBH;
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[i][(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
+                        } else {
+#pragma unroll
+                            for (int s = 0; s < 8; ++s) v[s] = h[i][2 * kb + (s >> 2)][s & 3];
+                        }
+                        bf3_split8(v, v1[i], v2[i], v3[i]);
+                    }
+                    if constexpr (kb == KBH + KBX - 1 && !bf3_abl(16)) {
+                        const int tn = t + 1 < a.T ? t + 1 : t;          // (the last step re-reads its own rows)
+                        load_x(tn, 0); load_x(tn, 1);
+                    }
+                }
+                auto mm = [&](const u32x4& fa0, const u32x4& fa1, const u32x4 (&v)[2]) {
+                    acc[0][j0] = bf3_mfma(fa0, v[0], acc[0][j0]); acc[0][j1] = bf3_mfma(fa1, v[0], acc[0][j1]);
+                    acc[1][j0] = bf3_mfma(fa0, v[1], acc[1][j0]); acc[1][j1] = bf3_mfma(fa1, v[1], acc[1][j1]);
+                };
+                bf3_rd<bf3_frag_off(KB, j0, kb, 0)>(ring[4], fa); bf3_rd<bf3_frag_off(KB, j1, kb, 0)>(ring[5], fa);
+                bf3_wait<4>(ring[0], ring[1]);
+                mm(ring[0], ring[1], v1);
+                if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 2)>(ring[1], fa); }
+                bf3_wait<last ? 2 : 4>(ring[2], ring[3]);
+                mm(ring[2], ring[3], v2);
+                mm(ring[2], ring[3], v1);
+                if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 1)>(ring[3], fa); }
+                bf3_wait<last ? 0 : 4>(ring[4], ring[5]);
+                mm(ring[4], ring[5], v3);
+                mm(ring[4], ring[5], v2);
+                mm(ring[4], ring[5], v1);
+            });
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (bf3_abl(4)) {
+                } else if (a.act == SGP_ACT_TANH) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
+                } else if (a.act == SGP_ACT_RELU) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
+                } else if (a.act == SGP_ACT_TANH_REL) {
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_rel(acc[i][jt][r]);
+                } else if (a.act == SGP_ACT_SELF_NORM) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) ss = fmaf(acc[i][jt][r], acc[i][jt][r], ss);
+                    ss += __shfl_xor(ss, 16);
+                    ss += __shfl_xor(ss, 32);
+                    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+                    for (int jt = 0; jt < JT; ++jt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[i][jt][r] *= inv;
+                }
+                char* op = reinterpret_cast<char*>(a.out + (long long)t * a.oss);
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha)
+                                                            : leak(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha);
+                    if (!bf3_abl(8) || t == 0) *reinterpret_cast<f32x4*>(op + oo[i] + 64 * jt) = h[i][jt];
+                }
+            }
+        }
+    };
+    if constexpr (PAIR) {
+        if (my_nt > 1) run_pair(); else run(Bf3C<1>{});
+    } else {
+        if (NT > 1 && my_nt > 1) run(Bf3C<NT>{}); else run(Bf3C<1>{});
+    }
     if (a.h_state) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)

@@ -1223,6 +1223,12 @@ int launch_layer(ResArgs a, hipStream_t s) {
         if (a.wp_bf3 && ov && xv && a.R == 16 * JT && a.F == 4 * NKX && n16 > 0 &&
             n16 * a.xrs * 4 < (1ll << 32) && n16 * a.ors * 4 < (1ll << 32)) {
             kern = reservoir_layer_bf3<JT, NKX, NT>;
+            if constexpr (NT == 2) {
+                // exact deal with at most three two-tile waves per SIMD (5 or 6 tiles): the two tiles share every
+                // fragment read (res_pair = 0, SGP_TUNE: one tile after the other)
+                static const bool pair = sgp::tune("res_pair", 1) != 0;
+                if (pair && a.tiles_per_wave > 0 && (a.tiles_per_wave + NT - 1) / NT <= 3) kern = reservoir_layer_bf3<JT, NKX, NT, true>;
+            }
             const int bytes = (int)bf3_packed_bytes(JT, NKX);
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

@@ -20,6 +20,8 @@ Library (integers)
                             operands); 0 = exact-fp32 MFMAs
     res_h16=1               small-N form, tanh: recurrent products from two fp16 pieces of the bounded state and of W_hh's scaled
                             rows (csrc/reservoir_splitj_bf3.h); 0 = three bf16 pieces there too
+    res_pair=1              large-N bf16-piece reservoir, 5-6 tiles per SIMD: a wave multiplies its two tiles against every fragment
+                            read (0: one tile after the other)
     res_tail_beside=1       the split-J tail of a large layer runs on a side lane beside the main part (0: after it)
     spmm_chunk=32           time steps per workgroup of the staged exact kernels
     spmm_variant=1          inner-loop variant of sgp_spmm_tiled_f32

@@ -168,9 +168,12 @@ def RESERVOIR_ARITHMETIC(R, F, N=None, activation="tanh"):
                 "(22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; input products: three bf16 pieces; fp32 "
                 "accumulation -- error vs fp64 equal to a CPU fp32 run's")
     if small or (R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128)):
-        if R == 64 and not small and activation == "tanh":
-            bf3 += ("; the <= 512 node tiles the exact deal leaves over run the small-N form beside it (its recurrent "
-                    "products from two fp16 pieces, include/sgp_amd.h)")
+        if R == 64 and not small:
+            # the <= 512 node tiles the exact deal of a large layer leaves over run the split-J form beside it
+            bf3 += ("; left-over node tiles of the exact deal: " +
+                    ("small-N form, recurrent products from two fp16 pieces (include/sgp_amd.h)"
+                     if F <= 32 and activation == "tanh" and tune.get("res_h16", 1, int) != 0 else
+                     "small-N form, three bf16 pieces" if F <= 32 else "exact fp32 MFMA (split-J)"))
         return bf3
     return "exact fp32 MFMA"
 

@@ -318,6 +318,11 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  * 2^-16 of its bound (1 for the state, the row's largest |w|), absolute 2^-38 of the bound below -- far under the
  * 3e-7 absolute accuracy of SGP_ACT_TANH itself.  A workgroup (16 nodes) whose INITIAL h_state has an entry outside
  * [-1, 1] (or NaN) runs the three-piece loop instead, decided on the device; the other activations always do.
+ * The large-N form (R = 32 / 64 with F = 16 / 32 / 64) does the same under SGP_ACT_TANH (pack_weights_bf3h: the row scale
+ * 2^(e_j + 14) is folded into the bias and the input fragments, so the accumulator carries it as a whole and is scaled
+ * back once, exactly): launched alone when h_state is NULL; with an h_state, a test kernel writes "some entry lies outside
+ * [-1, 1] or is NaN" into a device word and the two-piece instance runs under word == 0, the three-piece instance
+ * under word == 1 behind it (whole launch; no host round trip).
  * SGP_TUNE=res_h16=0 keeps three bf16 pieces for the bounded state too.
  */
 int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R);

@@ -82,6 +82,63 @@ __global__ void pack_weights_bf3(const float* __restrict__ w_ih, const float* __
 }
 
 
+// 1 into *bad when any of the n state values lies outside [-1, 1] or is NaN (the word is cleared by the launcher)
+__global__ void state_outside_unit_interval(const float* __restrict__ h, long long n, int* __restrict__ bad) {
+    int out = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        out |= !(fabsf(h[i]) <= 1.f);
+    if (__syncthreads_or(out) && threadIdx.x == 0) atomicOr(bad, 1);
+}
+
+// Large-N form of the bounded-state loop (reservoir_layer_bf3 with H16): pack_weights_bf3's layout with the recurrent blocks'
+// first two piece slots holding fp16 hi / lo of w_hh[j, :] 2^e_j, the input blocks and the bias as bf16 pieces / fp32 of
+// the values times 2^(e_j + 14) (the accumulator then carries that factor as a whole), and the way back 2^(-e_j - 14) of
+// the JT x 16 rows BEHIND the fragments.  Exact widths (R = 16 JT, F = 4 NKX).
+__global__ void pack_weights_bf3h(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                  const float* __restrict__ b, char* __restrict__ out, int F, int R, int JT, int NKX) {
+    const int KBH = bf3_kbh(JT), KB = KBH + bf3_kbx(NKX);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= JT * KB * 64) return;
+    const int l = i & 63, kb = (i >> 6) % KB, jt = (i >> 6) / KB;
+    const int j = 16 * jt + (l & 15), g = l >> 4;
+    float amax = 0.f;
+    for (int k = 0; k < R; ++k) amax = fmaxf(amax, fabsf(w_hh[(long long)j * R + k]));
+    int e = 0;
+    if (amax > 0.f && amax < __builtin_inff()) {
+        int k;
+        const float mant = frexpf(amax, &k);
+        e = (mant == 0.5f ? 15 : 14) - k;
+        e = min(40, max(-40, e));                              // (keeps 2^(e + 14) |w_ih x| far inside fp32)
+    }
+    const float ws = ldexpf(1.f, e), up = ldexpf(1.f, e + 14);
+    if (kb == 0 && g == 0) {
+        reinterpret_cast<float*>(out)[j] = b[j] * up;
+        reinterpret_cast<float*>(out + bf3_packed_bytes(JT, NKX))[j] = ldexpf(1.f, -e - 14);
+    }
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (kb < KBH) {
+            const int tt = 2 * kb + (s >> 2), k = 16 * tt + 4 * g + (s & 3);
+            w[s] = (tt < JT && k < R) ? w_hh[(long long)j * R + k] : 0.f;
+        } else {
+            const int ks = 8 * (kb - KBH) + s, k = bf3_feature(NKX, g, ks);
+            w[s] = (ks < NKX && k < F) ? w_ih[(long long)j * F + k] * up : 0.f;
+        }
+    }
+    u32x4* o = reinterpret_cast<u32x4*>(out + (long long)JT * 64) + ((long long)(jt * KB + kb) * 3) * 64 + l;
+    if (kb < KBH) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) sj16_split2(w[2 * d], w[2 * d + 1], ws, hi[d], lo[d]);
+        o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]}; o[64] = u32x4{lo[0], lo[1], lo[2], lo[3]}; o[128] = u32x4{0u, 0u, 0u, 0u};
+    } else {
+        u32x4 p1, p2, p3;
+        bf3_split8(w, p1, p2, p3);
+        o[0] = p1; o[64] = p2; o[128] = p3;
+    }
+}
+
 // Two-piece fp16 fragments of W_hh for the split-J kernel's bounded-state loop (reservoir_splitj_bf3.h): one thread per
 // (jt, kb, lane), row j scaled by the power of two that puts its largest entry at 2^13 .. 2^14 (computed here: a row is
 // at most 128 floats), 2^(-e_j - 14) -- the way back, the state's 2^14 included -- in front of the fragments.
@@ -171,6 +228,7 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
     return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
            (sjbf3_supported(jt, nkx) ? sj16_packed_bytes(jt) : 0) +
+           (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) + jt * 64 + 256 : 0) +     // (+ the state test's word)
            (sbf3_supported(jt, nkx) ? sbf3_packed_bytes(jt, nkx) + 1024 : 0);     // + dump area of the kernel
 }
 
@@ -202,6 +260,8 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     a.wp = (const float*)workspace;
     a.wp_bf3 = nullptr;
     a.wp_h16 = nullptr;
+    a.wp_h16l = nullptr;
+    a.bad_state = nullptr; a.pred = nullptr; a.pred_want = 0;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
     // (the split-J form for small N -- R = 64 / 128, up to 32 input features -- takes any R <= 16 jt, F <= 4 nkx: padded
@@ -222,6 +282,24 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
             rc = sgp::check_launch("pack_weights_sj16");
             if (rc) return rc;
             a.wp_h16 = wh;
+        }
+        if (use_h16 && bf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx && act == SGP_ACT_TANH) {
+            char* wl = wb + bf3_packed_bytes(jt, nkx) + (sjbf3_supported(jt, nkx) ? sj16_packed_bytes(jt) : 0);
+            hipLaunchKernelGGL(pack_weights_bf3h, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wl, F, R, jt, nkx);
+            rc = sgp::check_launch("pack_weights_bf3h");
+            if (rc) return rc;
+            a.wp_h16l = wl;
+            if (h_state) {
+                int* bad = reinterpret_cast<int*>(wl + bf3_packed_bytes(jt, nkx) + jt * 64);
+                hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
+                if (e != hipSuccess) return sgp::fail((int)e, "sgp_reservoir_f32: memset: %s", hipGetErrorString(e));
+                const long long n = (long long)N * R;
+                const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16) < 1024 ? (n + 256 * 16 - 1) / (256 * 16) : 1024);
+                hipLaunchKernelGGL(state_outside_unit_interval, dim3(blocks), dim3(256), 0, s, h_state, n, bad);
+                rc = sgp::check_launch("state_outside_unit_interval");
+                if (rc) return rc;
+                a.bad_state = bad;
+            }
         }
     }
     if (use_bf3 && sbf3_supported(jt, nkx) && R == 16 * jt && F == 4 * nkx) {

@@ -121,6 +121,30 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, v), acc, 0, 0, 0);
 }
 
+// fp16 two-piece products for a bounded state (arithmetic and error model: reservoir_splitj_bf3.h)
+constexpr float kSj16StateScale = 16384.f;
+// two scaled fp16 pieces of a pair of values (v_fma_mixlo / mixhi_f16: fp32 fma rounded once to fp16 into one half of
+// the destination; the remainder of an 11-bit rounding of a 24-bit value is exact in the fma)
+__device__ __forceinline__ void sj16_split2(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
+    hi = 0; lo = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
+}
+// the same with the (wave-uniform) scale in a scalar register
+__device__ __forceinline__ void sj16_split2s(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
+    hi = 0; lo = 0;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "s"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "s"(s), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "s"(s), "v"(hi));
+}
+__device__ __forceinline__ f32x4 sj16_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
+    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, v), acc, 0, 0, 0);
+}
+
 // Exact widths only (R = 16 JT, F = 4 NKX, 16-byte aligned rows): every load and store of the time loop is
 // unconditional and the loop body is straight-line code, so that the compiler counts its memory operations exactly
 // (s_waitcnt vmcnt(4) for the input rows with the four stores behind them still in flight).  With a branch around any
@@ -132,17 +156,15 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 
 // accumulators take turns behind every pair of fragments.  Measured N = 100 000, 256 steps: 3.46 -> 3.36 ms.  (The
 // `-DSGP_BF3_ABL=32` build without any fragment read runs at 2.75 ms, but on undefined operands: NaNs through the matrix
 // pipe draw less power and the clock rises -- the LDS is 28 % busy here, not the limit.)
-template <int JT, int NKX, int NT, bool PAIR = false>
+// H16 (tanh): the recurrent products from two fp16 pieces of the bounded state (reservoir_splitj_bf3.h has the arithmetic and
+// its error model; fragments and row scales of pack_weights_bf3h).  The launcher starts this instance under the launch
+// predicate "no initial state outside [-1, 1]" and the three-piece instance under the opposite one (ResArgs::pred).
+template <int JT, int NKX, int NT, bool PAIR = false, bool H16 = false>
 __global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_layer_bf3(ResArgs a) {
     static_assert(!PAIR || NT == 2, "the pair loop is written for two tiles per wave");
+    if (a.pred != nullptr && a.pred[0] != a.pred_want) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int KBH = bf3_kbh(JT), KBX = bf3_kbx(NKX), KB = KBH + KBX, NP = JT / 2, NU = KB * NP;
-    {
-        const int total4 = (int)(bf3_packed_bytes(JT, NKX) / 16);
-        for (int i = threadIdx.x; i < total4; i += blockDim.x)
-            reinterpret_cast<f32x4*>(lds)[i] = reinterpret_cast<const f32x4*>(a.wp_bf3)[i];
-        __syncthreads();
-    }
     const int lane = threadIdx.x & 63;
     const int n_in = lane & 15, q = lane >> 4;
     int tile0, tile1;                                        // the deal of reservoir_layer
@@ -161,8 +183,7 @@ __global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_lay
         tile0 = (int)((long long)wave * a.n_tiles / n_waves);
         tile1 = (int)((long long)(wave + 1) * a.n_tiles / n_waves);
     }
-    if (tile0 >= tile1) return;
-    const int my_nt = tile1 - tile0;
+    const int my_nt = max(tile1 - tile0, 0);
 
     // byte offsets of this lane's 16-byte piece of its node's input row / state row (32 bits: checked on the host)
     unsigned xo[NT], oo[NT];
@@ -178,6 +199,13 @@ __global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_lay
             if (a.h_state && i < my_nt) h[i][jt] = *reinterpret_cast<const f32x4*>(a.h_state + (long long)node * a.R + 16 * jt + 4 * q);
         }
     }
+    {
+        const f32x4* src = reinterpret_cast<const f32x4*>(H16 ? a.wp_h16l : a.wp_bf3);
+        const int total4 = (int)((bf3_packed_bytes(JT, NKX) + (H16 ? JT * 64 : 0)) / 16);
+        for (int i = threadIdx.x; i < total4; i += blockDim.x) reinterpret_cast<f32x4*>(lds)[i] = src[i];
+        __syncthreads();
+    }
+    if (my_nt == 0) return;
     // the input rows of ONE tile and step (register 4 k4 + s <-> feature 16 k4 + 4 q + s: the four lanes of a node read
     // 64 consecutive bytes per instruction): requested right after the rows before them were consumed (the input
     // part runs first), so they are in flight under the recurrent part, the activation and the stores of that tile
@@ -197,213 +225,181 @@ __global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_lay
     load_x(0, 0);
     if constexpr (PAIR) load_x(0, my_nt > 1 ? 1 : 0);
     const unsigned fa = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + JT * 16) + lane * 16;
+    float hscale = kSj16StateScale;
+    if constexpr (H16) asm("" : "+s"(hscale));            // (a register: v_fma_mix takes no literal)
 
-
-    auto run = [&](auto mtc) {
-        constexpr int MT = decltype(mtc)::value;
+    // The time loop for G tiles multiplied together (1, or 2 = PAIR), MT tiles per wave, H16 = fp16 pieces for the
+    // recurrent k-blocks.  A UNIT is (k-block, pair of output tiles); the input blocks come first.  Ring of six fragment
+    // registers: [0,1] = third pieces of the unit's two output tiles, [2,3] = second (H16 recurrent: lo), [4,5] = leading
+    // (hi).  An input unit multiplies 2 x (1 + 2 + 3) products per tile, a recurrent H16 unit 2 x (1 + 2), the output
+    // tiles' (and the G tiles') chains alternating (no MFMA waits for the one before it); the next unit's pieces are
+    // requested as soon as their registers are free.  LDS reads return in order: every wait counts the reads issued BEHIND
+    // the pair it needs.
+    auto run = [&](auto gc, auto mtc) {
+        constexpr int G = decltype(gc)::value, MT = decltype(mtc)::value;
+        auto rec = [](int u) constexpr { return H16 && bf3_unit_kb(JT, NKX, u) < KBH; };     // a two-piece fp16 unit
         for (int t = 0; t < a.T; ++t) {
             int wo = 0;                                      // keeps the bias reads inside the loop (see reservoir_layer)
-            asm volatile("" : "+v"(wo));
+            asm volatile("" : "+s"(wo));
             const float* bias_t = lds + wo;
 #pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                f32x4 acc[JT];
+            for (int i0 = 0; i0 < MT; i0 += G) {
+                f32x4 acc[G][JT];
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) acc[jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
-                // Ring of six fragment registers: [0,1] = third pieces of the unit's two output tiles, [2,3] = second,
-                // [4,5] = leading.  A unit multiplies 2 x (1 + 2 + 3) products, the two tiles' chains alternating (no
-                // MFMA waits for the one before it); the next unit's pieces are requested as soon as their registers
-                // are free: third pieces 10 MFMAs ahead of their use, second 8, leading 6.
+                for (int jt = 0; jt < JT; ++jt) {
+                    acc[0][jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
+                    if constexpr (G == 2) acc[1][jt] = acc[0][jt];
+                }
                 u32x4 ring[6];
                 bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 2)>(ring[1], fa);
                 bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 1)>(ring[3], fa);
-                u32x4 v1, v2, v3;
+                u32x4 v1[G], v2[G], v3[G];
                 bf3_for<0, NU>([&](auto uc) {
                     constexpr int u = decltype(uc)::value, kb = bf3_unit_kb(JT, NKX, u), j0 = 2 * (u % NP), j1 = j0 + 1;
-                    constexpr bool last = u + 1 == NU;
+                    constexpr bool last = u + 1 == NU, R = rec(u);
                     constexpr int un = last ? 0 : u + 1, kbn = bf3_unit_kb(JT, NKX, un), n0 = 2 * (un % NP), n1 = n0 + 1;
+                    constexpr bool Rn = !last && rec(un);        // the next unit is a two-piece one
+                    static_assert(u > 0 || !R, "the first unit is an input unit (its three pieces are requested ahead)");
                     if constexpr (u % NP == 0) {             // the pieces of a new k-block
-                        float v[8];
-                        if constexpr (kb >= KBH) {
-                            constexpr int p = kb - KBH;
 #pragma unroll
-                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[0][(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
-                        } else {
+                        for (int g = 0; g < G; ++g) {
+                            float v[8];
+                            if constexpr (kb >= KBH) {
+                                constexpr int p = kb - KBH;
 #pragma unroll
-                            for (int s = 0; s < 8; ++s) v[s] = h[i][2 * kb + (s >> 2)][s & 3];
-                        }
-                        if constexpr (bf3_abl(2)) {
+                                for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[PAIR ? g : 0][(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
+                            } else {
 #pragma unroll
-                            for (int d = 0; d < 4; ++d) { v1[d] = __builtin_bit_cast(unsigned, v[2 * d]); v2[d] = __builtin_bit_cast(unsigned, v[2 * d + 1]); v3[d] = v1[d] ^ v2[d]; }
-                        } else {
-                            bf3_split8(v, v1, v2, v3);
+                                for (int s = 0; s < 8; ++s) v[s] = h[i0 + g][2 * kb + (s >> 2)][s & 3];
+                            }
+                            if constexpr (R) {
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) {
+                                    unsigned hi, lo;
+                                    sj16_split2s(v[2 * d], v[2 * d + 1], hscale, hi, lo);
+                                    v1[g][d] = hi; v2[g][d] = lo;
+                                }
+                            } else if constexpr (bf3_abl(2)) {
+#pragma unroll
+                                for (int d = 0; d < 4; ++d) { v1[g][d] = __builtin_bit_cast(unsigned, v[2 * d]); v2[g][d] = __builtin_bit_cast(unsigned, v[2 * d + 1]); v3[g][d] = v1[g][d] ^ v2[g][d]; }
+                            } else {
+                                bf3_split8(v, v1[g], v2[g], v3[g]);
+                            }
                         }
                         if constexpr (kb == KBH + KBX - 1 && !bf3_abl(16)) {
                             // the input rows are consumed: request those of this wave's next tile and step (the last
                             // step re-reads its own rows instead of branching)
-                            if (i + 1 < MT) load_x(t, i + 1 < MT ? i + 1 : 0);
-                            else load_x(t + 1 < a.T ? t + 1 : t, 0);
+                            if constexpr (G == 2) {
+                                const int tn = t + 1 < a.T ? t + 1 : t;
+                                load_x(tn, 0); load_x(tn, 1);
+                            } else {
+                                if (i0 + 1 < MT) load_x(t, i0 + 1 < MT ? i0 + 1 : 0);
+                                else load_x(t + 1 < a.T ? t + 1 : t, 0);
+                            }
                         }
                     }
+                    auto mm = [&](const u32x4& f0, const u32x4& f1, const u32x4 (&v)[G]) {
+#pragma unroll
+                        for (int g = 0; g < G; ++g) {
+                            if constexpr (R) { acc[g][j0] = sj16_mfma(f0, v[g], acc[g][j0]); acc[g][j1] = sj16_mfma(f1, v[g], acc[g][j1]); }
+                            else { acc[g][j0] = bf3_mfma(f0, v[g], acc[g][j0]); acc[g][j1] = bf3_mfma(f1, v[g], acc[g][j1]); }
+                        }
+                    };
                     bf3_rd<bf3_frag_off(KB, j0, kb, 0)>(ring[4], fa); bf3_rd<bf3_frag_off(KB, j1, kb, 0)>(ring[5], fa);
-                    bf3_wait<4>(ring[0], ring[1]);
-                    acc[j0] = bf3_mfma(ring[0], v1, acc[j0]); acc[j1] = bf3_mfma(ring[1], v1, acc[j1]);
-                    if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 2)>(ring[1], fa); }
-                    bf3_wait<last ? 2 : 4>(ring[2], ring[3]);
-                    acc[j0] = bf3_mfma(ring[2], v2, acc[j0]); acc[j1] = bf3_mfma(ring[3], v2, acc[j1]);
-                    acc[j0] = bf3_mfma(ring[2], v1, acc[j0]); acc[j1] = bf3_mfma(ring[3], v1, acc[j1]);
+                    if constexpr (!R) {
+                        bf3_wait<4>(ring[0], ring[1]);
+                        mm(ring[0], ring[1], v1);
+                        if constexpr (!last && !Rn) { bf3_rd<bf3_frag_off(KB, n0, kbn, 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 2)>(ring[1], fa); }
+                    }
+                    bf3_wait<2 + (!R && !last && !Rn ? 2 : 0)>(ring[2], ring[3]);
+                    if constexpr (R) {
+                        mm(ring[2], ring[3], v1);                              // lo hi
+                    } else {
+                        mm(ring[2], ring[3], v2);
+                        mm(ring[2], ring[3], v1);
+                    }
                     if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 1)>(ring[3], fa); }
-                    bf3_wait<last ? 0 : 4>(ring[4], ring[5]);
-                    acc[j0] = bf3_mfma(ring[4], v3, acc[j0]); acc[j1] = bf3_mfma(ring[5], v3, acc[j1]);
-                    acc[j0] = bf3_mfma(ring[4], v2, acc[j0]); acc[j1] = bf3_mfma(ring[5], v2, acc[j1]);
-                    acc[j0] = bf3_mfma(ring[4], v1, acc[j0]); acc[j1] = bf3_mfma(ring[5], v1, acc[j1]);
+                    bf3_wait<(!last ? 2 : 0) + (!R && !last && !Rn ? 2 : 0)>(ring[4], ring[5]);
+                    if constexpr (R) {
+                        mm(ring[4], ring[5], v2);                              // hi lo
+                        mm(ring[4], ring[5], v1);                              // hi hi
+                    } else {
+                        mm(ring[4], ring[5], v3);
+                        mm(ring[4], ring[5], v2);
+                        mm(ring[4], ring[5], v1);
+                    }
                 });
-                // activation
-                if (bf3_abl(4)) {
-                } else if (a.act == SGP_ACT_TANH) {
+                if constexpr (H16) {
+                    // the rows' sums carry 2^(e_j + 14) (bias and input fragments were scaled to match): back, exactly
+                    const float* rsc_t = bias_t + (int)(bf3_packed_bytes(JT, NKX) / 4);
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                    for (int jt = 0; jt < JT; ++jt) {
+                        const f32x4 rs = *reinterpret_cast<const f32x4*>(rsc_t + jt * 16 + q * 4);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_r(acc[jt][r]);
-                } else if (a.act == SGP_ACT_RELU) {
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[jt][r] = fmaxf(acc[jt][r], 0.f);
-                } else if (a.act == SGP_ACT_TANH_REL) {
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[jt][r] = tanh_rel(acc[jt][r]);
-                } else if (a.act == SGP_ACT_SELF_NORM) {
-                    float ss = 0.f;
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) ss = fmaf(acc[jt][r], acc[jt][r], ss);
-                    ss += __shfl_xor(ss, 16);
-                    ss += __shfl_xor(ss, 32);
-                    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize(eps=1e-12)
-#pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[jt][r] *= inv;
-                }
-                // leak + store (64 bytes of each of 16 rows per instruction.  Swapping pieces between lanes n and n + 8 so
-                // that an instruction writes 8 whole 128-byte lines was measured: no gain, 3.60 vs 3.45-3.6 ms)
-                char* op = reinterpret_cast<char*>(a.out + (long long)t * a.oss);
-#pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
-                                                            : leak(h[i][jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
-                    if (!bf3_abl(8) || t == 0) *reinterpret_cast<f32x4*>(op + oo[i] + 64 * jt) = h[i][jt];
-                }
-            }
-        }
-    };
-    // two tiles in lockstep: the unit loop of `run` with every fragment multiplied against both tiles' pieces
-    auto run_pair = [&]() {
-        for (int t = 0; t < a.T; ++t) {
-            int wo = 0;
-            asm volatile("" : "+v"(wo));
-            const float* bias_t = lds + wo;
-            f32x4 acc[2][JT];
-#pragma unroll
-            for (int jt = 0; jt < JT; ++jt) acc[0][jt] = acc[1][jt] = *reinterpret_cast<const f32x4*>(bias_t + jt * 16 + q * 4);
-            u32x4 ring[6];
-            bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 2)>(ring[1], fa);
-            bf3_rd<bf3_frag_off(KB, 0, bf3_unit_kb(JT, NKX, 0), 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, 1, bf3_unit_kb(JT, NKX, 0), 1)>(ring[3], fa);
-            u32x4 v1[2], v2[2], v3[2];
-            bf3_for<0, NU>([&](auto uc) {
-                constexpr int u = decltype(uc)::value, kb = bf3_unit_kb(JT, NKX, u), j0 = 2 * (u % NP), j1 = j0 + 1;
-                constexpr bool last = u + 1 == NU;
-                constexpr int un = last ? 0 : u + 1, kbn = bf3_unit_kb(JT, NKX, un), n0 = 2 * (un % NP), n1 = n0 + 1;
-                if constexpr (u % NP == 0) {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        float v[8];
-                        if constexpr (kb >= KBH) {
-                            constexpr int p = kb - KBH;
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) v[s] = 8 * p + s < NKX ? xr[i][(8 * p + s < NKX ? 8 * p + s : 0) >> 2][s & 3] : 0.f;
-                        } else {
-#pragma unroll
-                            for (int s = 0; s < 8; ++s) v[s] = h[i][2 * kb + (s >> 2)][s & 3];
-                        }
-                        bf3_split8(v, v1[i], v2[i], v3[i]);
-                    }
-                    if constexpr (kb == KBH + KBX - 1 && !bf3_abl(16)) {
-                        const int tn = t + 1 < a.T ? t + 1 : t;          // (the last step re-reads its own rows)
-                        load_x(tn, 0); load_x(tn, 1);
+                        for (int g = 0; g < G; ++g) acc[g][jt] *= rs;
                     }
                 }
-                auto mm = [&](const u32x4& fa0, const u32x4& fa1, const u32x4 (&v)[2]) {
-                    acc[0][j0] = bf3_mfma(fa0, v[0], acc[0][j0]); acc[0][j1] = bf3_mfma(fa1, v[0], acc[0][j1]);
-                    acc[1][j0] = bf3_mfma(fa0, v[1], acc[1][j0]); acc[1][j1] = bf3_mfma(fa1, v[1], acc[1][j1]);
-                };
-                bf3_rd<bf3_frag_off(KB, j0, kb, 0)>(ring[4], fa); bf3_rd<bf3_frag_off(KB, j1, kb, 0)>(ring[5], fa);
-                bf3_wait<4>(ring[0], ring[1]);
-                mm(ring[0], ring[1], v1);
-                if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 2)>(ring[0], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 2)>(ring[1], fa); }
-                bf3_wait<last ? 2 : 4>(ring[2], ring[3]);
-                mm(ring[2], ring[3], v2);
-                mm(ring[2], ring[3], v1);
-                if constexpr (!last) { bf3_rd<bf3_frag_off(KB, n0, kbn, 1)>(ring[2], fa); bf3_rd<bf3_frag_off(KB, n1, kbn, 1)>(ring[3], fa); }
-                bf3_wait<last ? 0 : 4>(ring[4], ring[5]);
-                mm(ring[4], ring[5], v3);
-                mm(ring[4], ring[5], v2);
-                mm(ring[4], ring[5], v1);
-            });
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (bf3_abl(4)) {
-                } else if (a.act == SGP_ACT_TANH) {
+                for (int g = 0; g < G; ++g) {
+                    const int i = i0 + g;
+                    // activation
+                    if (bf3_abl(4)) {
+                    } else if (H16 || a.act == SGP_ACT_TANH) {
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_r(acc[i][jt][r]);
-                } else if (a.act == SGP_ACT_RELU) {
+                            for (int r = 0; r < 4; ++r) acc[g][jt][r] = tanh_r(acc[g][jt][r]);
+                    } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = fmaxf(acc[i][jt][r], 0.f);
-                } else if (a.act == SGP_ACT_TANH_REL) {
+                            for (int r = 0; r < 4; ++r) acc[g][jt][r] = fmaxf(acc[g][jt][r], 0.f);
+                    } else if (a.act == SGP_ACT_TANH_REL) {
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][jt][r] = tanh_rel(acc[i][jt][r]);
-                } else if (a.act == SGP_ACT_SELF_NORM) {
-                    float ss = 0.f;
+                            for (int r = 0; r < 4; ++r) acc[g][jt][r] = tanh_rel(acc[g][jt][r]);
+                    } else if (a.act == SGP_ACT_SELF_NORM) {
+                        float ss = 0.f;
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) ss = fmaf(acc[i][jt][r], acc[i][jt][r], ss);
-                    ss += __shfl_xor(ss, 16);
-                    ss += __shfl_xor(ss, 32);
-                    const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
+                            for (int r = 0; r < 4; ++r) ss = fmaf(acc[g][jt][r], acc[g][jt][r], ss);
+                        ss += __shfl_xor(ss, 16);
+                        ss += __shfl_xor(ss, 32);
+                        const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);   // F.normalize(eps=1e-12)
 #pragma unroll
-                    for (int jt = 0; jt < JT; ++jt)
+                        for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) acc[i][jt][r] *= inv;
-                }
-                char* op = reinterpret_cast<char*>(a.out + (long long)t * a.oss);
+                            for (int r = 0; r < 4; ++r) acc[g][jt][r] *= inv;
+                    }
+                    // leak + store (64 bytes of each of 16 rows per instruction.  Swapping pieces between lanes n and n + 8 so
+                    // that an instruction writes 8 whole 128-byte lines was measured: no gain, 3.60 vs 3.45-3.6 ms)
+                    // (scalar base + 32-bit lane offset, like the input rows: a 64-bit pointer per lane and tile did not fit)
+                    unsigned long long ob = (unsigned long long)(a.out + (long long)t * a.oss);
+                    asm volatile("" : "+s"(ob));
+                    typedef __attribute__((address_space(1))) char* gptr;
+                    const gptr op = (gptr)ob;
+                    // (vector copies made HERE: as loop invariants the pairs {alpha, alpha} .. of the packed fmas were spilled and
+                    // reloaded every step behind an s_waitcnt vmcnt(0))
+                    float al = a.alpha, om = a.one_minus_alpha;
+                    asm volatile("" : "+v"(al), "+v"(om));
 #pragma unroll
-                for (int jt = 0; jt < JT; ++jt) {
+                    for (int jt = 0; jt < JT; ++jt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        h[i][jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha)
-                                                            : leak(h[i][jt][r], acc[i][jt][r], a.alpha, a.one_minus_alpha);
-                    if (!bf3_abl(8) || t == 0) *reinterpret_cast<f32x4*>(op + oo[i] + 64 * jt) = h[i][jt];
+                        for (int r = 0; r < 4; ++r)
+                            h[i][jt][r] = (H16 || a.act == SGP_ACT_TANH) ? leak_tanh_r(h[i][jt][r], acc[g][jt][r], al, om)
+                                                                        : leak(h[i][jt][r], acc[g][jt][r], al, om);
+                        if (!bf3_abl(8) || t == 0) *reinterpret_cast<__attribute__((address_space(1))) f32x4*>(op + oo[i] + 64 * jt) = h[i][jt];
+                    }
                 }
             }
         }
     };
     if constexpr (PAIR) {
-        if (my_nt > 1) run_pair(); else run(Bf3C<1>{});
+        if (my_nt > 1) run(Bf3C<2>{}, Bf3C<2>{}); else run(Bf3C<1>{}, Bf3C<1>{});
     } else {
-        if (NT > 1 && my_nt > 1) run(Bf3C<NT>{}); else run(Bf3C<1>{});
+        if (NT > 1 && my_nt > 1) run(Bf3C<1>{}, Bf3C<NT>{}); else run(Bf3C<1>{}, Bf3C<1>{});
     }
     if (a.h_state) {
 #pragma unroll

@@ -69,6 +69,9 @@ struct ResArgs {
     const float* wp;                 // packed weights (global workspace)
     const void* wp_bf3;              // the same weights as bf16 piece fragments (reservoir_bf3.h), or null
     const void* wp_h16;              // W_hh as scaled two-piece fp16 fragments (reservoir_splitj_bf3.h), or null
+    const void* wp_h16l;             // large-N form of the same: pack_weights_bf3h's buffer (reservoir_bf3.h), or null
+    const int* bad_state;            // device word: 1 = some initial state lies outside [-1, 1] (null: no initial state given)
+    const int* pred; int pred_want;  // launch predicate of reservoir_layer_bf3 (the kernel exits unless *pred == pred_want)
     float* out; long long ors, oss;
     float* h_state;
     float alpha, one_minus_alpha;
@@ -1222,28 +1225,45 @@ int launch_layer(ResArgs a, hipStream_t s) {
         const long long n16 = a.N / 16 * 16;
         if (a.wp_bf3 && ov && xv && a.R == 16 * JT && a.F == 4 * NKX && n16 > 0 &&
             n16 * a.xrs * 4 < (1ll << 32) && n16 * a.ors * 4 < (1ll << 32)) {
+            void (*kern16)(ResArgs) = reservoir_layer_bf3<JT, NKX, NT, false, true>;     // two fp16 pieces for the bounded state
             kern = reservoir_layer_bf3<JT, NKX, NT>;
             if constexpr (NT == 2) {
                 // exact deal with at most three two-tile waves per SIMD (5 or 6 tiles): the two tiles share every
                 // fragment read (res_pair = 0, SGP_TUNE: one tile after the other)
                 static const bool pair = sgp::tune("res_pair", 1) != 0;
-                if (pair && a.tiles_per_wave > 0 && (a.tiles_per_wave + NT - 1) / NT <= 3) kern = reservoir_layer_bf3<JT, NKX, NT, true>;
+                if (pair && a.tiles_per_wave > 0 && (a.tiles_per_wave + NT - 1) / NT <= 3) {
+                    kern = reservoir_layer_bf3<JT, NKX, NT, true>;
+                    kern16 = reservoir_layer_bf3<JT, NKX, NT, true, true>;
+                }
             }
-            const int bytes = (int)bf3_packed_bytes(JT, NKX);
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-            if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+            const int bytes = (int)bf3_packed_bytes(JT, NKX) + JT * 64;       // (+ the row scales of the two-piece fp16 form)
+            for (auto k : {kern, kern16}) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+                if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
+            }
             ResArgs m = a;
             m.N = (int)n16;
             m.n_tiles = (int)(n16 / 16);
             if (a.tiles_per_wave <= 0 && m.n_tiles <= 1024) grid = m.n_tiles;
             // as many waves per SIMD as share its tiles evenly (6 tiles: 3 waves of 2; same time as 2 + 2 + 1 + 1 on 4)
             if (a.tiles_per_wave > 0) wpw = 4 * ((a.tiles_per_wave + NT - 1) / NT);
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)bytes, s, m);
+            // tanh with packed fp16 fragments: the two-piece instance -- alone when the recurrence starts from zero, else under
+            // the device word "some initial state lies outside [-1, 1]" == 0 with the three-piece instance under == 1
+            // behind it (no host round trip; the instance whose predicate fails exits at its first instruction)
+            m.pred = nullptr; m.pred_want = 0;
+            if (a.wp_h16l) {
+                m.pred = a.bad_state; m.pred_want = 0;
+                hipLaunchKernelGGL(kern16, dim3(grid), dim3(64 * wpw), (size_t)bytes, s, m);
+                int rc16 = sgp::check_launch("reservoir_layer_bf3 (fp16 pieces)");
+                if (rc16) return rc16;
+                m.pred_want = 1;
+            }
+            if (!a.wp_h16l || a.bad_state) hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * wpw), (size_t)bytes, s, m);
             int rc = sgp::check_launch("reservoir_layer_bf3");
             if (rc || n16 == a.N) return rc;
             ResArgs r = a;                                   // the last, ragged tile
-            r.wp_bf3 = nullptr;
+            r.wp_bf3 = nullptr; r.wp_h16l = nullptr;
             r.tiles_per_wave = 0;
             r.x = a.x + n16 * a.xrs;
             r.out = a.out + n16 * a.ors;

@@ -38,7 +38,6 @@ __host__ __device__ constexpr bool sjbf3_supported(int JT, int NKX) { return (JT
 // fp16 fragments of the recurrent blocks: [JT x 16 row scales 2^(-e_j - 14)] [JT][KBH][2 pieces][64 lanes][16 B]
 __host__ __device__ constexpr long long sj16_packed_bytes(int JT) { return JT * 64ll + (long long)JT * bf3_kbh(JT) * 2 * 1024; }
 __host__ __device__ constexpr int sj16_frag_off(int KBH, int jt, int kb, int pc) { return ((jt * KBH + kb) * 2 + pc) * 1024; }
-constexpr float kSj16StateScale = 16384.f;
 // LDS: piece slab [2][3][KBH][64][16 B] | self_norm partials [2][64] | input ring [PFD][NKX][64]
 __host__ __device__ constexpr long long sjbf3_slab_bytes(int JT) { return 2ll * 3 * bf3_kbh(JT) * 1024; }
 __host__ __device__ constexpr int sjbf3_ring(int JT, int NKX) { return 8; }
@@ -58,20 +57,6 @@ constexpr bool sj_abl(int bit) { return (SGP_SJ_ABL & bit) != 0; }
 
 // ACT >= 0: the activation is known at compile time (the tanh instance carries no activation dispatch in its time loop:
 // the run-time form spent ~40 scalar branches per step on it), -1: read from the arguments
-// two scaled fp16 pieces of a pair of values (v_fma_mixlo / mixhi_f16: fp32 fma rounded once to fp16 into one half of
-// the destination; the remainder of an 11-bit rounding of a 24-bit value is exact in the fma)
-__device__ __forceinline__ void sj16_split2(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
-    hi = 0; lo = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "v"(s), "v"(hi));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
-}
-__device__ __forceinline__ f32x4 sj16_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
-    typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, v), acc, 0, 0, 0);
-}
-
 template <int JT, int NKX, bool OVEC, int ACT, bool H16>
 __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one input k-block");

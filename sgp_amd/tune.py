@@ -18,8 +18,8 @@ Library (integers)
     res_bf3=1               reservoirs with R = 32 / 64 (F = 16 / 32 / 64) and R = 256 (F = 32 / 64 / 128): products from three bf16
                             pieces per operand on the 16-bit matrix cores (csrc/reservoir_bf3.h; fp32-grade, no bound on the
                             operands); 0 = exact-fp32 MFMAs
-    res_h16=1               small-N form, tanh: recurrent products from two fp16 pieces of the bounded state and of W_hh's scaled
-                            rows (csrc/reservoir_splitj_bf3.h); 0 = three bf16 pieces there too
+    res_h16=1               bf16-piece reservoirs, tanh: recurrent products from two fp16 pieces of the bounded state and of W_hh's
+                            scaled rows (csrc/reservoir_splitj_bf3.h, reservoir_bf3.h); 0 = three bf16 pieces there too
     res_pair=1              large-N bf16-piece reservoir, 5-6 tiles per SIMD: a wave multiplies its two tiles against every fragment
                             read (0: one tile after the other)
     res_tail_beside=1       the split-J tail of a large layer runs on a side lane beside the main part (0: after it)

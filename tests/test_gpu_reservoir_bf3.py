@@ -242,3 +242,66 @@ def test_split_j_two_piece_fp16_loop_is_the_one_that_runs():
         assert p.returncode == 0, p.stderr[-2000:]
         hashes.append([l for l in p.stdout.splitlines() if l.startswith("HASH")][0])
     assert hashes[0] != hashes[1]
+
+
+@pytest.mark.parametrize("n,f,r", [(16384 * 6 + 16 * 200, 64, 64), (20000, 32, 32), (16 * 1024 * 2 + 16 * 37 + 5, 64, 64)])
+def test_large_n_two_piece_fp16_state_under_the_launch_predicate(n, f, r):
+    """The large-N form of the bounded-state loop (reservoir_layer_bf3<.., H16>: recurrent products from two fp16 pieces,
+    the row scale folded into bias and input fragments, sgp_amd.h): chosen ON THE DEVICE -- alone when the recurrence
+    starts from zero, under the word "some initial state lies outside [-1, 1]" == 0 when a state is handed in, with
+    the three-piece instance under == 1 behind it.  Rows of W_hh five orders of magnitude apart; a state inside the
+    interval, one with a single entry of 1.5, one with a NaN: each as close to fp64 as the CPU's fp32 run."""
+    hip.require_gpu()
+    torch.manual_seed(n % 97)
+    t = 20
+    res = sgp_amd.Reservoir(f, r, spectral_radius=0.9, leaking_rate=0.8)
+    layer = res.reservoir_layers[0]
+    assert float(layer.b_ih.abs().max()) >= 0.25           # activation code tanh: the fp16 loop is eligible
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        layer.w_hh.data = (layer.w_hh.data * 10.0 ** (torch.rand(r, 1, generator=g) * 5 - 4)).contiguous()
+        layer.w_hh.data *= 0.9 / float(torch.linalg.eigvals(layer.w_hh.data).abs().max())
+    x = torch.randn(t, n, f)
+    xg = x.cuda()
+    nodes = sorted({0, 1, 15, 16, 17, n // 3, n // 2, n - 17, n - 16, n - 2, n - 1} | set(range(4096, 4096 + 24)))
+    idx = torch.as_tensor(nodes)
+
+    def run(h0):
+        state = None if h0 is None else h0.clone().cuda()
+        out = torch.full((t, n, r), float("nan"), device="cuda")
+        res.encode_into(xg, out, state)
+        if state is not None:
+            assert torch.equal(state[0], out[-1]) or bool(torch.isnan(state).any())
+        return out
+
+    def check_against_fp64(out, h0, skip=()):
+        keep = [k for k, v in enumerate(nodes) if v not in skip]
+        sel = idx[keep]
+        kw = {} if h0 is None else dict(h0=h0[:, sel])
+        ref64 = O.reservoir_forward(x[:, sel], layers_of(res), dtype=torch.float64, **kw)
+        ref32 = O.reservoir_forward(x[:, sel], layers_of(res), **kw)
+        got = out[:, sel.cuda()].cpu()
+        assert torch.isfinite(got).all()
+        e_gpu = float((got.double() - ref64).abs().max())
+        e_cpu = float((ref32.double() - ref64).abs().max())
+        assert e_gpu <= 2 * e_cpu + 1e-6, (e_gpu, e_cpu)
+        assert O.rel_fro(got, ref32) <= 1e-5
+
+    zero = run(None)
+    check_against_fp64(zero, None)
+    h_in = torch.rand(1, n, r) * 2 - 1
+    inside = run(h_in)
+    check_against_fp64(inside, h_in)
+    h_out = h_in.clone()
+    h_out[0, n // 2, 3] = 1.5                                # one entry: the whole launch takes the three-piece instance
+    outside = run(h_out)
+    check_against_fp64(outside, h_out)
+    # (same data except one node: the two instances differ in the low bits elsewhere -- the predicate switched kernels)
+    far = [v for v in nodes if v != n // 2]
+    assert not torch.equal(outside[:, far], inside[:, far])
+    assert float((outside[:, far] - inside[:, far]).abs().max()) < 1e-5
+    h_nan = h_in.clone()
+    h_nan[0, 17, 0] = float("nan")
+    with_nan = run(h_nan)
+    assert bool(torch.isnan(with_nan[:, 17]).any())
+    check_against_fp64(with_nan, h_nan, skip=(17,))

@@ -168,7 +168,7 @@ def RESERVOIR_ARITHMETIC(R, F, N=None, activation="tanh"):
                 "(22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; input products: three bf16 pieces; fp32 "
                 "accumulation -- error vs fp64 equal to a CPU fp32 run's")
     if small or (R in (32, 64) and F in (16, 32, 64)) or (R == 256 and F in (32, 64, 128)):
-        if not small and R in (32, 64) and activation == "tanh" and tune.get("res_h16", 1, int) != 0:
+        if not small and (R in (32, 64) or (R == 256 and (N or 0) >= 2048 * 16)) and activation == "tanh" and tune.get("res_h16", 1, int) != 0:
             bf3 = ("recurrent products: state (|h| <= 1, x 2^14) and W_hh (per-row power-of-two scale) as two fp16 pieces "
                    "(22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; input products: three bf16 pieces, six terms; "
                    "fp32 accumulation -- error vs fp64 equal to a CPU fp32 run's")

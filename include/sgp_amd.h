@@ -318,7 +318,7 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  * 2^-16 of its bound (1 for the state, the row's largest |w|), absolute 2^-38 of the bound below -- far under the
  * 3e-7 absolute accuracy of SGP_ACT_TANH itself.  A workgroup (16 nodes) whose INITIAL h_state has an entry outside
  * [-1, 1] (or NaN) runs the three-piece loop instead, decided on the device; the other activations always do.
- * The large-N form (R = 32 / 64 with F = 16 / 32 / 64) does the same under SGP_ACT_TANH (pack_weights_bf3h: the row scale
+ * The large-N forms (R = 32 / 64 with F = 16 / 32 / 64; R = 256 with F = 32 / 64 / 128, >= 2048 node tiles) do the same under SGP_ACT_TANH (pack_weights_bf3h / pack_weights_sbf3h: the row scale
  * 2^(e_j + 14) is folded into the bias and the input fragments, so the accumulator carries it as a whole and is scaled
  * back once, exactly): launched alone when h_state is NULL; with an h_state, a test kernel writes "some entry lies outside
  * [-1, 1] or is NaN" into a device word and the two-piece instance runs under word == 0, the three-piece instance

@@ -202,6 +202,62 @@ __global__ void pack_weights_sbf3(const float* __restrict__ w_ih, const float* _
     o[0] = p1; o[64] = p2; o[128] = p3;
 }
 
+// Wide form of the bounded-state loop (reservoir_layer_stream_bf3 with H16): pack_weights_sbf3's streamed layout with the
+// recurrent sub-blocks as [tile][2 fp16 pieces] in the first 16 of their 24 KB, bias and input fragments times 2^(e_j + 14)
+// (pack_weights_bf3h), the rows' 2^(-e_j - 14) behind the kernel's dump area.
+__global__ void pack_weights_sbf3h(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+                                   const float* __restrict__ b, char* __restrict__ out, int F, int R, int JT, int NKX) {
+    const int KBH = JT / 2, KBX = NKX / 8, NSB = 2 * (KBH + KBX);     // input k-blocks first
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    auto row_exp = [&](int j) {
+        float amax = 0.f;
+        for (int k = 0; k < R; ++k) amax = fmaxf(amax, fabsf(w_hh[(long long)j * R + k]));
+        int e = 0;
+        if (amax > 0.f && amax < __builtin_inff()) {
+            int k;
+            const float mant = frexpf(amax, &k);
+            e = (mant == 0.5f ? 15 : 14) - k;
+            e = min(40, max(-40, e));
+        }
+        return e;
+    };
+    if (i < JT * 16) {
+        const int e = i < R ? row_exp(i) : 0;
+        reinterpret_cast<float*>(out)[i] = i < R ? b[i] * ldexpf(1.f, e + 14) : 0.f;
+        reinterpret_cast<float*>(out + sbf3_packed_bytes(JT, NKX) + 1024)[i] = ldexpf(1.f, -e - 14);
+    }
+    if (i >= NSB * 8 * 64) return;
+    const int l = i & 63, j8 = (i >> 6) & 7, sb = i >> 9;
+    const int kb = sb >> 1, jt = 8 * (sb & 1) + j8;
+    const int j = 16 * jt + (l & 15), g = l >> 4;
+    const int e = j < R ? row_exp(j) : 0;
+    const float ws = ldexpf(1.f, e), up = ldexpf(1.f, e + 14);
+    float w[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        if (kb >= KBX) {
+            const int k = 16 * (2 * (kb - KBX) + (s >> 2)) + 4 * g + (s & 3);
+            w[s] = (j < R && k < R) ? w_hh[(long long)j * R + k] : 0.f;
+        } else {
+            const int k = bf3_feature(NKX, g, 8 * kb + s);
+            w[s] = (j < R && k < F) ? w_ih[(long long)j * F + k] * up : 0.f;
+        }
+    }
+    char* slot = out + 1024 + (long long)sb * (8 * 3 * 1024);
+    if (kb >= KBX) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) sj16_split2(w[2 * d], w[2 * d + 1], ws, hi[d], lo[d]);
+        u32x4* o = reinterpret_cast<u32x4*>(slot) + (long long)(j8 * 2) * 64 + l;
+        o[0] = u32x4{hi[0], hi[1], hi[2], hi[3]}; o[64] = u32x4{lo[0], lo[1], lo[2], lo[3]};
+    } else {
+        u32x4 p1, p2, p3;
+        bf3_split8(w, p1, p2, p3);
+        u32x4* o = reinterpret_cast<u32x4*>(slot) + (long long)(j8 * 3) * 64 + l;
+        o[0] = p1; o[64] = p2; o[128] = p3;
+    }
+}
+
 long long bf3_offset(int jt, int nkx) { return (packed_floats(jt, nkx) * 4 + 255) / 256 * 256; }
 
 int pick_nkx(int F) {
@@ -229,7 +285,8 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
            (sjbf3_supported(jt, nkx) ? sj16_packed_bytes(jt) : 0) +
            (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) + jt * 64 + 256 : 0) +     // (+ the state test's word)
-           (sbf3_supported(jt, nkx) ? sbf3_packed_bytes(jt, nkx) + 1024 : 0);     // + dump area of the kernel
+           (sbf3_supported(jt, nkx) ? 2 * (sbf3_packed_bytes(jt, nkx) + 1024) + 1024 + 256 : 0);   // + dump areas of the kernel; the
+                                                                                   // two-piece fp16 copy + its row scales + the state test's word
 }
 
 int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
@@ -256,11 +313,22 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     if (rc) return rc;
 
     ResArgs a;
+    // the device word "some initial state lies outside [-1, 1] (or is NaN)" for the two-piece fp16 instances' launch predicate
+    auto test_state = [&](int* bad) -> int {
+        hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
+        if (e != hipSuccess) return sgp::fail((int)e, "sgp_reservoir_f32: memset: %s", hipGetErrorString(e));
+        const long long n = (long long)N * R;
+        const long long want = (n + 256 * 16 - 1) / (256 * 16);
+        hipLaunchKernelGGL(state_outside_unit_interval, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, s, h_state, n, bad);
+        int rc2 = sgp::check_launch("state_outside_unit_interval");
+        if (!rc2) a.bad_state = bad;
+        return rc2;
+    };
     a.x = x; a.xrs = xrs; a.xss = xss;
     a.wp = (const float*)workspace;
     a.wp_bf3 = nullptr;
     a.wp_h16 = nullptr;
-    a.wp_h16l = nullptr;
+    a.wp_h16l = nullptr; a.wp_h16s = nullptr;
     a.bad_state = nullptr; a.pred = nullptr; a.pred_want = 0;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
@@ -290,15 +358,8 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
             if (rc) return rc;
             a.wp_h16l = wl;
             if (h_state) {
-                int* bad = reinterpret_cast<int*>(wl + bf3_packed_bytes(jt, nkx) + jt * 64);
-                hipError_t e = hipMemsetAsync(bad, 0, sizeof(int), s);
-                if (e != hipSuccess) return sgp::fail((int)e, "sgp_reservoir_f32: memset: %s", hipGetErrorString(e));
-                const long long n = (long long)N * R;
-                const int blocks = (int)((n + 256 * 16 - 1) / (256 * 16) < 1024 ? (n + 256 * 16 - 1) / (256 * 16) : 1024);
-                hipLaunchKernelGGL(state_outside_unit_interval, dim3(blocks), dim3(256), 0, s, h_state, n, bad);
-                rc = sgp::check_launch("state_outside_unit_interval");
+                rc = test_state(reinterpret_cast<int*>(wl + bf3_packed_bytes(jt, nkx) + jt * 64));
                 if (rc) return rc;
-                a.bad_state = bad;
             }
         }
     }
@@ -309,6 +370,18 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
         rc = sgp::check_launch("pack_weights_sbf3");
         if (rc) return rc;
         a.wp_bf3 = wb;
+        static const bool use_h16s = sgp::tune("res_h16", 1) != 0;
+        if (use_h16s && act == SGP_ACT_TANH) {
+            char* wh = wb + sbf3_packed_bytes(jt, nkx) + 1024;
+            hipLaunchKernelGGL(pack_weights_sbf3h, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wh, F, R, jt, nkx);
+            rc = sgp::check_launch("pack_weights_sbf3h");
+            if (rc) return rc;
+            a.wp_h16s = wh;
+            if (h_state) {
+                rc = test_state(reinterpret_cast<int*>(wh + sbf3_packed_bytes(jt, nkx) + 2048));
+                if (rc) return rc;
+            }
+        }
     }
     a.out = out; a.ors = ors; a.oss = oss;
     a.h_state = h_state;

@@ -70,6 +70,7 @@ struct ResArgs {
     const void* wp_bf3;              // the same weights as bf16 piece fragments (reservoir_bf3.h), or null
     const void* wp_h16;              // W_hh as scaled two-piece fp16 fragments (reservoir_splitj_bf3.h), or null
     const void* wp_h16l;             // large-N form of the same: pack_weights_bf3h's buffer (reservoir_bf3.h), or null
+    const void* wp_h16s;             // wide (R = 256) form of the same: pack_weights_sbf3h's buffer, or null
     const int* bad_state;            // device word: 1 = some initial state lies outside [-1, 1] (null: no initial state given)
     const int* pred; int pred_want;  // launch predicate of reservoir_layer_bf3 (the kernel exits unless *pred == pred_want)
     float* out; long long ors, oss;
@@ -740,19 +741,30 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream8(ResArgs a) {
 // requested one piece per sub-block once the input k-blocks of step t are done, and every s_waitcnt counts exactly the
 // operations issued since the fetch it needs (all loads and stores unconditional: lanes without a node read row 0 and
 // store to a dump area behind the packed weights).
-template <int JT, int NKX>
+// H16 (tanh, launched under the predicate of reservoir_layer_bf3's H16 instance): the recurrent sub-blocks hold two fp16
+// pieces per fragment (16 of their 24 KB: two DMA pieces per wave instead of three) and multiply three products per tile
+// instead of six; the accumulators carry the rows' 2^(e_j + 14) (pack_weights_sbf3h) and are scaled back once per step.
+template <int JT, int NKX, bool H16 = false>
 __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) {
     static_assert(sbf3_supported(JT, NKX), "stream bf3 kernel: R = 256, F = 32 .. 128");
+    if (a.pred != nullptr && a.pred[0] != a.pred_want) return;
     constexpr int RING = 4, AHEAD = 3;
     constexpr int KBH = JT / 2, KBX = NKX / 8, NSB = 2 * (KBH + KBX);    // sub-blocks per step: (k-block, half), input first
     constexpr int NXL = NKX / 4;                         // 16-byte input loads per lane and step
     constexpr int SLOT = 8 * 3 * 1024;                   // bytes per sub-block
-    constexpr int PPW = 3;                               // 1-KiB pieces of a sub-block per wave
+    constexpr int PPW = 3;                               // 1-KiB pieces of a (three-piece) sub-block per wave
+    auto two = [](int sb) constexpr { return H16 && sb >= 2 * KBX; };          // a two-piece (recurrent fp16) sub-block
+    auto ppw = [two](int sb) constexpr { return two(sb) ? 2 : 3; };
     static_assert(NSB >= JT && 2 * KBX + NXL <= NSB, "one store / one load per sub-block");
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* bias_l = lds + RING * SLOT / 4;               // after the ring slots
-    const char* wpb = static_cast<const char*>(a.wp_bf3);
-    for (int i = threadIdx.x; i < JT * 16; i += 512) bias_l[i] = reinterpret_cast<const float*>(wpb)[i];
+    float* bias_l = lds + RING * SLOT / 4;               // after the ring slots (H16: + the rows' way back behind it)
+    const char* wpb = static_cast<const char*>(H16 ? a.wp_h16s : a.wp_bf3);
+    for (int i = threadIdx.x; i < JT * 16; i += 512) {
+        bias_l[i] = reinterpret_cast<const float*>(wpb)[i];
+        if constexpr (H16) bias_l[JT * 16 + i] = reinterpret_cast<const float*>(wpb + sbf3_packed_bytes(JT, NKX) + 1024)[i];
+    }
+    float hscale = kSj16StateScale;
+    if constexpr (H16) asm("" : "+s"(hscale));
 
     const int lane = threadIdx.x & 63;
     const int n_in = lane & 15, q = lane >> 4;
@@ -780,17 +792,20 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
     const unsigned voff = (unsigned)lane * 16u;
     const unsigned lds_w = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(PPW * wv) * 1024u);
     const char* src_w = wpb + 1024 + (long long)(PPW * wv) * 1024;
-    auto fetch_piece = [&](int sb, int pos, int p) {     // this wave's piece p of sub-block sb into ring position pos
-        const char* sp = src_w;
-        unsigned l0 = lds_w;
+    const unsigned lds_w2 = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(2 * wv) * 1024u);      // (two-piece sub-blocks: 16 pieces)
+    const char* src_w2 = wpb + 1024 + (long long)(2 * wv) * 1024;
+    auto fetch_piece = [&](int sb, int pos, int p, bool tw) {     // this wave's piece p of sub-block sb into ring position pos
+        const char* sp = tw ? src_w2 : src_w;
+        unsigned l0 = tw ? lds_w2 : lds_w;
         asm volatile("" : "+s"(sp), "+s"(l0));
         const unsigned slot = l0 + (unsigned)(pos & (RING - 1)) * SLOT;
         if constexpr (bf3_abl(64)) return;               // experiment: no weight stream
         res_dma16(sp + (long long)sb * SLOT + p * 1024, voff, slot + (unsigned)p * 1024u);
     };
-    auto fetch = [&](int sb, int pos) {
+    auto fetch = [&](int sb, int pos, int np) {
 #pragma unroll
-        for (int p = 0; p < PPW; ++p) fetch_piece(sb, pos, p);
+        for (int p = 0; p < PPW; ++p)
+            if (p < np) fetch_piece(sb, pos, p, np == 2);
     };
     // input rows: register 4 k4 + s <-> feature 16 k4 + 4 q + s (bf3_feature); loaded by hand so that the compiler
     // puts no s_waitcnt of its own between the counted ones
@@ -801,8 +816,7 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
     };
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // initial-state loads retired
     __syncthreads();
-#pragma unroll
-    for (int b = 0; b < AHEAD; ++b) fetch(b, b);
+    static_for<0, AHEAD>([&](auto bc) { constexpr int b = decltype(bc)::value; fetch(b, b, ppw(b)); });
 #pragma unroll
     for (int k4 = 0; k4 < NXL; ++k4) load_x(k4, 0);
     int cnt = 0;                                         // sub-blocks consumed so far (ring position of the next one)
@@ -815,7 +829,7 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
 
     // memory operations a wave issues in sub-block sb, after its barrier: the 3 DMA pieces of sub-block sb + 3, one
     // 16-byte-per-lane store of the state of the step before (sb < JT), one input load for the next step
-    auto ops = [](int sb) constexpr { return PPW + (sb < JT ? 1 : 0) + (sb >= 2 * KBX && sb < 2 * KBX + NXL ? 1 : 0); };
+    auto ops = [ppw](int sb) constexpr { return ppw((sb + AHEAD) % NSB) + (sb < JT ? 1 : 0) + (sb >= 2 * KBX && sb < 2 * KBX + NXL ? 1 : 0); };
 
     for (int t = 0; t <= a.T; ++t) {                     // iteration T only stores the last state
         f32x4 acc[JT];
@@ -836,8 +850,9 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
             // the pieces of sub-block sb + 3 go into the slot of sub-block sb - 1, which every wave has left; a busy
             // wave requests them one per pair of output tiles INSIDE its MFMA phase (an issue that stalls on a full
             // memory queue then waits under queued matrix work, not in front of it)
-            const int fsb = (sb + AHEAD) % NSB, fpos = cnt + AHEAD;
-            if (!(busy && real)) fetch(fsb, fpos);
+            constexpr int fsb = (sb + AHEAD) % NSB;
+            const int fpos = cnt + AHEAD;
+            if (!(busy && real)) fetch(fsb, fpos, ppw(fsb));
             const u32x4* slot = reinterpret_cast<const u32x4*>(lds + (cnt & (RING - 1)) * (SLOT / 4)) + lane;
             ++cnt;
             const u32x4* next_slot = reinterpret_cast<const u32x4*>(lds + (cnt & (RING - 1)) * (SLOT / 4)) + lane;
@@ -852,36 +867,66 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
 #pragma unroll
                         for (int s = 0; s < 8; ++s) v[s] = h[2 * (blk - KBX) + (s >> 2)][s & 3];
                     }
-                    if constexpr (bf3_abl(2)) {
+                    constexpr bool R = two(sb);
+                    if constexpr (R) {
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) {
+                            unsigned hi, lo;
+                            sj16_split2s(v[2 * d], v[2 * d + 1], hscale, hi, lo);
+                            v1[d] = hi; v2[d] = lo;
+                        }
+                    } else if constexpr (bf3_abl(2)) {
 #pragma unroll
                         for (int d = 0; d < 4; ++d) { v1[d] = __builtin_bit_cast(unsigned, v[2 * d]); v2[d] = __builtin_bit_cast(unsigned, v[2 * d + 1]); v3[d] = v1[d] ^ v2[d]; }
                     } else {
                         bf3_split8(v, v1, v2, v3);
                     }
                 }
-                // fragment (tile j8 of this half, piece pc) = slot[(j8 * 3 + pc) * 64].  Pairs of tiles, their chains
-                // alternating; the leading pieces multiply first, so that each of the six fragment registers is free
-                // for the next pair's piece 6-10 MFMAs before that is used (no second set of registers)
-#pragma unroll
-                for (int jp = 0; jp < 4; ++jp) {
-                    const u32x4* nx = jp + 1 < 4 ? slot + (jp + 1) * 6 * 64 : next_slot;
+                // fragment (tile j8 of this half, piece pc) = slot[(j8 * NP + pc) * 64], NP = 3 pieces (2 in a two-piece
+                // sub-block).  Pairs of tiles, their chains alternating; the leading pieces multiply first, so that each of
+                // the six fragment registers is free for the next pair's piece 6-10 MFMAs before that is used (no second
+                // set of registers).  f[3 tile + pc]; a two-piece pair leaves f[2], f[5] alone.
+                constexpr bool R = two(sb), Rn = two((sb + 1) % NSB);
+                constexpr int NPc = R ? 2 : 3;
+                static_for<0, 4>([&](auto jc) {
+                    constexpr int jp = decltype(jc)::value;
+                    constexpr bool lastp = jp == 3, Rx = lastp ? Rn : R;      // the pair whose fragments are requested now
+                    constexpr int NPx = Rx ? 2 : 3;
+                    const u32x4* nx = lastp ? next_slot : slot + (jp + 1) * 2 * NPc * 64;
+                    auto ldf = [&](auto kc) {
+                        constexpr int k = decltype(kc)::value;
+                        if constexpr (!bf3_abl(32)) f[k] = nx[((k / 3) * NPx + (k % 3)) * 64];
+                    };
                     f32x4& A = acc[8 * half + 2 * jp];
                     f32x4& B = acc[8 * half + 2 * jp + 1];
-                    A = bf3_mfma(f[0], v3, A); B = bf3_mfma(f[3], v3, B);
-                    A = bf3_mfma(f[0], v2, A); B = bf3_mfma(f[3], v2, B);
-                    A = bf3_mfma(f[0], v1, A); B = bf3_mfma(f[3], v1, B);
-                    if constexpr (!bf3_abl(32)) { f[0] = nx[0]; f[3] = nx[3 * 64]; }
-                    A = bf3_mfma(f[1], v2, A); B = bf3_mfma(f[4], v2, B);
-                    A = bf3_mfma(f[1], v1, A); B = bf3_mfma(f[4], v1, B);
-                    if constexpr (!bf3_abl(32)) { f[1] = nx[64]; f[4] = nx[4 * 64]; }
-                    A = bf3_mfma(f[2], v1, A); B = bf3_mfma(f[5], v1, B);
-                    if constexpr (!bf3_abl(32)) { f[2] = nx[2 * 64]; f[5] = nx[5 * 64]; }
-                    if (jp < PPW) fetch_piece(fsb, fpos, jp);
-                }
+                    if constexpr (!R) {
+                        A = bf3_mfma(f[0], v3, A); B = bf3_mfma(f[3], v3, B);
+                        A = bf3_mfma(f[0], v2, A); B = bf3_mfma(f[3], v2, B);
+                        A = bf3_mfma(f[0], v1, A); B = bf3_mfma(f[3], v1, B);
+                        ldf(Bf3C<0>{}); ldf(Bf3C<3>{});
+                        A = bf3_mfma(f[1], v2, A); B = bf3_mfma(f[4], v2, B);
+                        A = bf3_mfma(f[1], v1, A); B = bf3_mfma(f[4], v1, B);
+                        ldf(Bf3C<1>{}); ldf(Bf3C<4>{});
+                        A = bf3_mfma(f[2], v1, A); B = bf3_mfma(f[5], v1, B);
+                        if constexpr (!Rx) { ldf(Bf3C<2>{}); ldf(Bf3C<5>{}); }
+                    } else {
+                        A = sj16_mfma(f[1], v1, A); B = sj16_mfma(f[4], v1, B);        // lo hi
+                        ldf(Bf3C<1>{}); ldf(Bf3C<4>{});
+                        A = sj16_mfma(f[0], v2, A); B = sj16_mfma(f[3], v2, B);        // hi lo
+                        A = sj16_mfma(f[0], v1, A); B = sj16_mfma(f[3], v1, B);        // hi hi
+                        ldf(Bf3C<0>{}); ldf(Bf3C<3>{});
+                        if constexpr (!Rx) { ldf(Bf3C<2>{}); ldf(Bf3C<5>{}); }            // (an input pair comes next: its third pieces)
+                    }
+                    if constexpr (jp < ppw(fsb)) fetch_piece(fsb, fpos, jp, two(fsb));
+                });
             }
         });
         if (busy && real) {
-            if (a.act == SGP_ACT_TANH) {
+            if constexpr (H16) {
+#pragma unroll
+                for (int jt = 0; jt < JT; ++jt) acc[jt] *= *reinterpret_cast<const f32x4*>(bias_l + JT * 16 + jt * 16 + q * 4);
+            }
+            if (H16 || a.act == SGP_ACT_TANH) {
 #pragma unroll
                 for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
@@ -914,8 +959,8 @@ __global__ __launch_bounds__(512, 2) void reservoir_layer_stream_bf3(ResArgs a) 
             for (int jt = 0; jt < JT; ++jt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    h[jt][r] = a.act == SGP_ACT_TANH ? leak_tanh_r(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
-                                                     : leak(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
+                    h[jt][r] = (H16 || a.act == SGP_ACT_TANH) ? leak_tanh_r(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha)
+                                                              : leak(h[jt][r], acc[jt][r], a.alpha, a.one_minus_alpha);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the sub-blocks and rows requested ahead of the end
@@ -943,8 +988,21 @@ int launch_stream(ResArgs a, hipStream_t s) {
     void (*kern)(ResArgs) = eight ? reservoir_layer_stream8<JT, NKX, true, true> : reservoir_layer_stream<JT, NKX, true, true>;
     int bytes = 4 * JT * 1024 + JT * 16 * 4;                 // RING slots + bias
     bool bf3 = false;
+    a.pred = nullptr; a.pred_want = 0;
     if constexpr (sbf3_supported(JT, NKX)) {
-        if (a.wp_bf3) { kern = reservoir_layer_stream_bf3<JT, NKX>; bytes = 4 * 8 * 3 * 1024 + JT * 16 * 4; bf3 = true; }
+        if (a.wp_bf3) { kern = reservoir_layer_stream_bf3<JT, NKX>; bytes = 4 * 8 * 3 * 1024 + 2 * JT * 16 * 4; bf3 = true; }
+        if (a.wp_bf3 && a.wp_h16s) {
+            // tanh: the two-piece fp16 instance, alone or under the initial-state word == 0 with the three-piece one behind it
+            void (*kern16)(ResArgs) = reservoir_layer_stream_bf3<JT, NKX, true>;
+            hipError_t e16 = hipFuncSetAttribute(reinterpret_cast<const void*>(kern16),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+            if (e16 != hipSuccess) return sgp::fail((int)e16, "reservoir: LDS opt-in: %s", hipGetErrorString(e16));
+            a.pred = a.bad_state; a.pred_want = 0;
+            hipLaunchKernelGGL(kern16, dim3(full + tail_wgs), dim3(512), (size_t)bytes, s, a);
+            int rc16 = sgp::check_launch("reservoir_layer_stream_bf3 (fp16 pieces)");
+            if (rc16 || !a.bad_state) return rc16;
+            a.pred_want = 1;
+        }
     }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);

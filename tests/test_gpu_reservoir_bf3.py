@@ -244,7 +244,8 @@ def test_split_j_two_piece_fp16_loop_is_the_one_that_runs():
     assert hashes[0] != hashes[1]
 
 
-@pytest.mark.parametrize("n,f,r", [(16384 * 6 + 16 * 200, 64, 64), (20000, 32, 32), (16 * 1024 * 2 + 16 * 37 + 5, 64, 64)])
+@pytest.mark.parametrize("n,f,r", [(16384 * 6 + 16 * 200, 64, 64), (20000, 32, 32), (16 * 1024 * 2 + 16 * 37 + 5, 64, 64),
+                                   (2048 * 16 + 16 * 5 + 3, 64, 256), (40000, 32, 256)])    # R = 256: the streamed form (>= 2048 node tiles)
 def test_large_n_two_piece_fp16_state_under_the_launch_predicate(n, f, r):
     """The large-N form of the bounded-state loop (reservoir_layer_bf3<.., H16>: recurrent products from two fp16 pieces,
     the row scale folded into bias and input fragments, sgp_amd.h): chosen ON THE DEVICE -- alone when the recurrence

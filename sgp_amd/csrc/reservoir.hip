@@ -282,11 +282,13 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     const int jt = pick_jt(R), nkx = pick_nkx(F);
     if (!jt || !nkx) return -1;
     // the fp32 fragments, then (narrow reservoirs) the bf16 piece fragments of reservoir_bf3.h
-    return bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
+    const long long body =
+           bf3_offset(jt, nkx) + (bf3_supported(jt, nkx) || sjbf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) : 0) +
            (sjbf3_supported(jt, nkx) ? sj16_packed_bytes(jt) : 0) +
            (bf3_supported(jt, nkx) ? bf3_packed_bytes(jt, nkx) + jt * 64 + 256 : 0) +     // (+ the state test's word)
            (sbf3_supported(jt, nkx) ? 2 * (sbf3_packed_bytes(jt, nkx) + 1024) + 1024 + 256 : 0);   // + dump areas of the kernel; the
                                                                                    // two-piece fp16 copy + its row scales + the state test's word
+    return (body + 255) / 256 * 256 + 1024;                                        // + the split-J form's dump area (last KB)
 }
 
 int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
@@ -329,6 +331,7 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     a.wp_bf3 = nullptr;
     a.wp_h16 = nullptr;
     a.wp_h16l = nullptr; a.wp_h16s = nullptr;
+    a.dump = reinterpret_cast<float*>((char*)workspace + sgp_reservoir_workspace_bytes(F, R) - 1024);
     a.bad_state = nullptr; a.pred = nullptr; a.pred_want = 0;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;

@@ -71,6 +71,7 @@ struct ResArgs {
     const void* wp_h16;              // W_hh as scaled two-piece fp16 fragments (reservoir_splitj_bf3.h), or null
     const void* wp_h16l;             // large-N form of the same: pack_weights_bf3h's buffer (reservoir_bf3.h), or null
     const void* wp_h16s;             // wide (R = 256) form of the same: pack_weights_sbf3h's buffer, or null
+    float* dump;                     // 1 KB of device scratch: unconditional stores of lanes that own no row (split-J bf16 form)
     const int* bad_state;            // device word: 1 = some initial state lies outside [-1, 1] (null: no initial state given)
     const int* pred; int pred_want;  // launch predicate of reservoir_layer_bf3 (the kernel exits unless *pred == pred_want)
     float* out; long long ors, oss;

@@ -126,33 +126,54 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     }
     const unsigned xring_lds = __builtin_amdgcn_readfirstlane(
         (unsigned)(size_t)(__attribute__((address_space(3))) float*)xring);
-    auto dma_x = [&](int t) {
-        const float* xp = a.x + (long long)min(t, a.T - 1) * a.xss;
-        const unsigned base = xring_lds + (unsigned)((t % PFD) * NKX * 256);
+    // running request state of wave 0: the rows of steps 0, 1, 2, .. in turn (the last step's row again beyond it); one
+    // wave per SIMD pays ~5 cycles for every instruction, so the 64-bit products t x stride are replaced by additions
+    const float* xsrc[NKX];
+#pragma unroll
+    for (int ks = 0; ks < NKX; ++ks) xsrc[ks] = a.x + x_off[ks];
+    int x_next = 0;                                       // step whose row is requested next
+    unsigned x_slot = 0;                                  // its ring slot (x_next % PFD)
+    auto dma_next = [&]() {
+        const unsigned base = xring_lds + x_slot * (unsigned)(NKX * 256);
+        const long long inc = x_next < a.T - 1 ? a.xss : 0;
 #pragma unroll
         for (int ks = 0; ks < NKX; ++ks) {
-            const float* src = xp + x_off[ks];
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off"
-                         :: "v"(src), "s"(base + (unsigned)ks * 256u) : "memory");
+                         :: "v"(xsrc[ks]), "s"(base + (unsigned)ks * 256u) : "memory");
+            xsrc[ks] += inc;
         }
+        ++x_next;
+        x_slot = x_slot + 1 == (unsigned)PFD ? 0u : x_slot + 1;
     };
     bool st_ok[JW];
 #pragma unroll
     for (int w = 0; w < JW; ++w) st_ok[w] = ok && 16 * (wave * JW + w) + 4 * q < a.R;
     float* orow = a.out + (long long)node * a.ors + 16 * (wave * JW) + 4 * q;       // this lane's piece of step 0's row
-    auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
-        float* ot = orow + (long long)t * a.oss;
+    // OVEC: every lane stores 16 bytes per tile and step, unconditionally -- lanes without a row (or a padded unit) into a
+    // dump area behind the packed weights -- through a running pointer: no exec-masked branch, no 64-bit product per step
+    float* optr[JW];
+    long long oinc[JW];
 #pragma unroll
-        for (int w = 0; w < JW; ++w) {
-            const int j0 = 16 * (wave * JW + w) + 4 * q;
-            if (st_ok[w]) {
-                float* op = ot + 16 * w;
-                if constexpr (OVEC) {
-                    *reinterpret_cast<f32x4*>(op) = hv[w];
-                } else {
+    for (int w = 0; w < JW; ++w) {
+        optr[w] = st_ok[w] ? orow + 16 * w : a.dump + lane * 4;
+        oinc[w] = st_ok[w] ? a.oss : 0;
+    }
+    auto store_h = [&](int t, const f32x4 (&hv)[JW]) {
+        if constexpr (OVEC) {
+#pragma unroll
+            for (int w = 0; w < JW; ++w) {
+                *reinterpret_cast<f32x4*>(optr[w]) = hv[w];
+                optr[w] += oinc[w];
+            }
+        } else {
+            float* ot = orow + (long long)t * a.oss;
+#pragma unroll
+            for (int w = 0; w < JW; ++w) {
+                const int j0 = 16 * (wave * JW + w) + 4 * q;
+                if (st_ok[w]) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (j0 + r < a.R) op[r] = hv[w][r];
+                        if (j0 + r < a.R) ot[16 * w + r] = hv[w][r];
                 }
             }
         }
@@ -183,7 +204,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     for (int w = 0; w < JW; ++w) publish(1, w, hown[w]);  // step 0 reads parity 1
     __syncthreads();                                     // initial pieces in LDS
     if (wave == 0) {
-        for (int p = 0; p < PFD - 1; ++p) dma_x(p);
+        for (int p = 0; p < PFD - 1; ++p) dma_next();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // rows 0 .. PFD-2 published
@@ -222,7 +243,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
 
     for (int t = 0; t < a.T; ++t) {
         if (t > 0 && !sj_abl(1)) store_h(t - 1, hown);
-        if (wave == 0) dma_x(t + PFD - 1);               // into the slot consumed one step ago
+        if (wave == 0) dma_next();                       // the row of step t + PFD - 1, into the slot consumed one step ago
         // B operands: the state pieces of step t - 1 (all tiles), leading pieces of every k-block first (the first round
         // of products needs exactly those)
         u32x4 V[KBH][3];

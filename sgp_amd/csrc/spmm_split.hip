@@ -50,7 +50,7 @@ using sgp::f32x4;
 #define SGP_SPLIT_NW 16
 #endif
 constexpr int NW = SGP_SPLIT_NW;             // waves per workgroup, 16 rows each
-static_assert(NW == 12 || NW == 16, "12 or 16 waves x 16 rows");
+static_assert(NW == 8 || NW == 12 || NW == 16, "8, 12 or 16 waves x 16 rows");
 #ifndef SGP_SPLIT_NCH
 #define SGP_SPLIT_NCH 7
 #endif

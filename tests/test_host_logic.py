@@ -463,3 +463,21 @@ def test_sgp_tune_is_one_hook_read_alike_by_python_and_the_library(monkeypatch):
     assert lib.sgp_tune_value(b"chunk", 5) == 5                       # a suffix of a key is not the key
     with pytest.raises(ValueError):
         tune.get("hop", 1, int)
+
+
+def test_small_graph_pipeline_pieces_follow_the_hops_share_of_the_chain(monkeypatch):
+    """SGPEncoder._overlap_pieces (host logic of encode_device): 16 time pieces where the hops take as long as the
+    reservoir chain (PEMS-BAY settings), 4 where they are a seventh of it (METR-LA settings), one piece for short
+    sequences, for graphs beyond `overlap_tiles` node tiles, and when SGP_TUNE overrides the count."""
+    monkeypatch.delenv("SGP_TUNE", raising=False)
+    bay = sgp_amd.SGPEncoder(input_size=3, reservoir_size=128, reservoir_layers=1, leaking_rate=.8, spectral_radius=.9,
+                             density=.7, input_scaling=1., receptive_field=4, bidirectional=True, alpha_decay=False,
+                             global_attr=True)
+    la = sgp_amd.SGPEncoder(input_size=3, reservoir_size=64, reservoir_layers=1, leaking_rate=.9, spectral_radius=.9,
+                            density=.7, input_scaling=1., receptive_field=2, bidirectional=False, alpha_decay=False,
+                            global_attr=False)
+    assert bay._overlap_pieces(52116, 325) == 16 and la._overlap_pieces(34272, 207) == 4
+    assert bay._overlap_pieces(1000, 325) == 1                # fewer than 64 steps per piece
+    assert bay._overlap_pieces(52116, 16 * bay.overlap_tiles + 1) == 1
+    monkeypatch.setenv("SGP_TUNE", "overlap_chunks=2")
+    assert bay._overlap_pieces(52116, 325) == 2 and la._overlap_pieces(34272, 207) == 2

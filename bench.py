@@ -162,7 +162,7 @@ def RESERVOIR_ARITHMETIC(R, F, N=None, activation="tanh"):
         return "exact fp32 MFMA"
     bf3 = ("operands as three bf16 pieces (24 bits, no scale), six 16-bit MFMA terms per product, fp32 accumulation "
            "-- error vs fp64 equal to a CPU fp32 run's")
-    small = N is not None and (N + 15) // 16 <= 512 and 32 < R <= 128 and F <= 32      # split-J form (reservoir_splitj_bf3.h)
+    small = N is not None and (N + 15) // 16 <= 512 and 32 < R <= 128 and F <= 64      # split-J form (reservoir_splitj_bf3.h)
     if small and activation == "tanh" and tune.get("res_h16", 1, int) != 0:
         return ("recurrent products: state (|h| <= 1, x 2^14) and W_hh (per-row power-of-two scale) as two fp16 pieces "
                 "(22 bits), hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16; input products: three bf16 pieces; fp32 "
@@ -176,8 +176,8 @@ def RESERVOIR_ARITHMETIC(R, F, N=None, activation="tanh"):
             # the <= 512 node tiles the exact deal of a large layer leaves over run the split-J form beside it
             bf3 += ("; left-over node tiles of the exact deal: " +
                     ("small-N form, recurrent products from two fp16 pieces (include/sgp_amd.h)"
-                     if F <= 32 and activation == "tanh" and tune.get("res_h16", 1, int) != 0 else
-                     "small-N form, three bf16 pieces" if F <= 32 else "exact fp32 MFMA (split-J)"))
+                     if F <= 64 and activation == "tanh" and tune.get("res_h16", 1, int) != 0 else
+                     "small-N form, three bf16 pieces" if F <= 64 else "exact fp32 MFMA (split-J)"))
         return bf3
     return "exact fp32 MFMA"
 

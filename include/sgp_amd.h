@@ -310,7 +310,7 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  * three bf16 pieces (24 bits, no scale, no bound on the values), six piece products per product on
  * v_mfma_f32_16x16x32_bf16, fp32 accumulation -- as close to the fp64 result as a CPU fp32 evaluation
  * (tests/test_gpu_reservoir_bf3.py); SGP_TUNE=res_bf3=0 keeps the fp32 matrix cores for them too.
- * Small problems (<= 512 tiles of 16 nodes, 32 < R <= 128, F <= 32: csrc/reservoir_splitj_bf3.h) form the same
+ * Small problems (<= 512 tiles of 16 nodes, 32 < R <= 128, F <= 64: csrc/reservoir_splitj_bf3.h) form the same
  * three-piece products, except the RECURRENT ones under act = SGP_ACT_TANH: there the state lies in [-1, 1] (a convex
  * combination of the old state and a tanh) and is cut into two fp16 pieces of 2^14 h, row j of w_hh into two fp16
  * pieces under its own power-of-two scale (largest entry at 2^13 .. 2^14); hi hi + hi lo + lo hi on

@@ -20,7 +20,7 @@
 // The accumulation of a tile is cut into independent chains (added at the end) with the chain index as the inner
 // loop, so that no MFMA waits for the result of the one before it.
 //
-// Widths: R <= 16 JT, F <= 4 NKX with NKX <= 8 (one input k-block), any N, T; padded units / features carry zero
+// Widths: R <= 16 JT, F <= 4 NKX with NKX <= 8 (one input k-block) or NKX = 16 (two), any N, T; padded units / features carry zero
 // weights and zero operands, stores are masked like the fp32 kernel's.
 
 //
@@ -34,7 +34,7 @@
 // keeps its three bf16 pieces (x is not bounded).  A workgroup whose INITIAL state leaves [-1, 1] (a caller's own
 // h_state) runs the three-piece loop instead: the choice is made per workgroup at the top of the kernel.
 
-__host__ __device__ constexpr bool sjbf3_supported(int JT, int NKX) { return (JT == 4 || JT == 8) && NKX <= 8; }
+__host__ __device__ constexpr bool sjbf3_supported(int JT, int NKX) { return (JT == 4 || JT == 8) && (NKX <= 8 || NKX == 16); }
 // fp16 fragments of the recurrent blocks: [JT x 16 row scales 2^(-e_j - 14)] [JT][KBH][2 pieces][64 lanes][16 B]
 __host__ __device__ constexpr long long sj16_packed_bytes(int JT) { return JT * 64ll + (long long)JT * bf3_kbh(JT) * 2 * 1024; }
 __host__ __device__ constexpr int sj16_frag_off(int KBH, int jt, int kb, int pc) { return ((jt * KBH + kb) * 2 + pc) * 1024; }
@@ -59,12 +59,12 @@ constexpr bool sj_abl(int bit) { return (SGP_SJ_ABL & bit) != 0; }
 // the run-time form spent ~40 scalar branches per step on it), -1: read from the arguments
 template <int JT, int NKX, bool OVEC, int ACT, bool H16>
 __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
-    static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one input k-block");
+    static_assert(sjbf3_supported(JT, NKX), "R = 64 / 128 (padded), one or two input k-blocks");
     const int act = ACT >= 0 ? ACT : a.act;
     float alpha_v = a.alpha;              // a VGPR copy for the leak: hipcc 7.2 emitted v_fma_f32 with BOTH scalars (alpha, 1 - alpha)
     asm("" : "+v"(alpha_v));              // as operands in this kernel ("violates constant bus restriction")
     constexpr int JW = JT / 4;                           // output tiles per wave
-    constexpr int KBH = bf3_kbh(JT), KB = KBH + 1;       // recurrent k-blocks (two state tiles each) + the input block
+    constexpr int KBH = bf3_kbh(JT), KBX = bf3_kbx(NKX), KB = KBH + KBX;   // recurrent k-blocks (two state tiles each) + the input block(s)
     constexpr int PFD = sjbf3_ring(JT, NKX);
     extern __shared__ __attribute__((aligned(16))) char lds_raw[];
     char* slab = lds_raw;                                                  // [2][3][KBH][64][16]
@@ -210,15 +210,19 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // rows 0 .. PFD-2 published
 
     // pieces of the input row of step 0 (rows 0 .. PFD - 2 are published)
-    u32x4 X[3];
+    u32x4 X[KBX][3];
     auto input_pieces = [&](int t) {
         const float* xrow = xring + (t % PFD) * NKX * 64;
-        float xv[8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xv[ks] = 0.f;
+        for (int kx = 0; kx < KBX; ++kx) {
+            float xv[8];
 #pragma unroll
-        for (int ks = 0; ks < NKX; ++ks) xv[ks] = x_ok[ks] ? xrow[ks * 64 + lane] : 0.f;
-        bf3_split8(xv, X[0], X[1], X[2]);
+            for (int s8 = 0; s8 < 8; ++s8) {
+                const int ks = 8 * kx + s8;
+                xv[s8] = ks < NKX && x_ok[ks < NKX ? ks : 0] ? xrow[(ks < NKX ? ks : 0) * 64 + lane] : 0.f;
+            }
+            bf3_split8(xv, X[kx][0], X[kx][1], X[kx][2]);
+        }
     };
     input_pieces(0);
     // The input block does not depend on the state: its six products of step t + 1 are issued at the END of step t, behind
@@ -233,11 +237,14 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int w = 0; w < JW; ++w) {
-                    const f32x4 c0 = h == 0 ? bias[w] : f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (!sj_abl(32)) accx[w][h] = bf3_mfma(W[w][KBH][PW[3 * h + i]], X[PV[3 * h + i]], i == 0 ? c0 : accx[w][h]);
-                    else if (i == 0) accx[w][h] = c0;
-                }
+                for (int kx = 0; kx < KBX; ++kx)
+#pragma unroll
+                    for (int w = 0; w < JW; ++w) {
+                        const f32x4 c0 = h == 0 ? bias[w] : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const bool first = i == 0 && kx == 0;
+                        if (!sj_abl(32)) accx[w][h] = bf3_mfma(W[w][KBH + kx][PW[3 * h + i]], X[kx][PV[3 * h + i]], first ? c0 : accx[w][h]);
+                        else if (first) accx[w][h] = c0;
+                    }
     };
     input_block();
 

@@ -128,6 +128,9 @@ def test_bf3_wide_reservoir_short_sequences_strided_rows_and_state(t):
     (77, 20, 50, "tanh", 60),           # F = 20: the 16-byte feature order of the wider input blocks; ragged last tile
     (8190, 3, 64, "tanh", 40),          # 512 node tiles: the largest problem the split-J form serves alone
     (1000, 32, 128, "tanh", 40),        # a full input k-block
+    (3000, 64, 128, "tanh", 40),        # two input k-blocks (F = 64)
+    (500, 40, 64, "relu", 40),          # two input k-blocks, the second one padded (F = 40 of 64)
+    (8000, 64, 64, "tanh", 30),         # 500 node tiles, F = R = 64
 ])
 def test_split_j_bf3_small_graphs(n, f, r, act, t):
     """The small-N form (reservoir_splitj_bf3.h: one node tile per workgroup, the output tiles split over its four

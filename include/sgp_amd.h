@@ -323,6 +323,7 @@ int32_t sgp_spmm_tiled_max_row_edges(void);
  * back once, exactly): launched alone when h_state is NULL; with an h_state, a test kernel writes "some entry lies outside
  * [-1, 1] or is NaN" into a device word and the two-piece instance runs under word == 0, the three-piece instance
  * under word == 1 behind it (whole launch; no host round trip).
+ * All of this only for 0 <= alpha <= 1 (the leak is convex); any other leaking rate keeps three bf16 pieces.
  * SGP_TUNE=res_h16=0 keeps three bf16 pieces for the bounded state too.
  */
 int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R);

@@ -345,7 +345,10 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
         if (rc) return rc;
         a.wp_bf3 = wb;
         // res_h16 = 0 (SGP_TUNE) keeps three bf16 pieces for the bounded (tanh) state of the split-J form too
-        static const bool use_h16 = sgp::tune("res_h16", 1) != 0;
+        // (the state stays in [-1, 1] only under a convex leak: a leaking rate outside [0, 1], which the reference accepts,
+        // keeps three bf16 pieces)
+        static const bool h16_on = sgp::tune("res_h16", 1) != 0;
+        const bool use_h16 = h16_on && alpha >= 0.0 && alpha <= 1.0;
         if (use_h16 && sjbf3_supported(jt, nkx) && act == SGP_ACT_TANH) {
             char* wh = wb + bf3_packed_bytes(jt, nkx);
             const int th = jt * bf3_kbh(jt) * 64;
@@ -373,8 +376,8 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
         rc = sgp::check_launch("pack_weights_sbf3");
         if (rc) return rc;
         a.wp_bf3 = wb;
-        static const bool use_h16s = sgp::tune("res_h16", 1) != 0;
-        if (use_h16s && act == SGP_ACT_TANH) {
+        static const bool h16s_on = sgp::tune("res_h16", 1) != 0;
+        if (h16s_on && act == SGP_ACT_TANH && alpha >= 0.0 && alpha <= 1.0) {
             char* wh = wb + sbf3_packed_bytes(jt, nkx) + 1024;
             hipLaunchKernelGGL(pack_weights_sbf3h, dim3((threads + 255) / 256), dim3(256), 0, s, w_ih, w_hh, b, wh, F, R, jt, nkx);
             rc = sgp::check_launch("pack_weights_sbf3h");

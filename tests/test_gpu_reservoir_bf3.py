@@ -309,3 +309,19 @@ def test_large_n_two_piece_fp16_state_under_the_launch_predicate(n, f, r):
     with_nan = run(h_nan)
     assert bool(torch.isnan(with_nan[:, 17]).any())
     check_against_fp64(with_nan, h_nan, skip=(17,))
+
+
+@pytest.mark.parametrize("n,f,r", [(325, 3, 128), (20000, 64, 64), (2048 * 16 + 40, 64, 256)])
+def test_leaking_rate_outside_the_unit_interval_keeps_three_pieces(n, f, r):
+    """A leaking rate of 1.7 (the reference takes any float, reservoir.py:109-123): |h| reaches 1.7 / 0.3 = 5.7 -- outside the
+    range the two-piece fp16 state is scaled for.  The library keeps three bf16 pieces there: as close to fp64 as the
+    CPU's fp32 run."""
+    hip.require_gpu()
+    torch.manual_seed(r + 1)
+    res = sgp_amd.Reservoir(f, r, spectral_radius=0.5, leaking_rate=1.7)
+    t = 60
+    x = torch.randn(t, n, f)
+    out = torch.full((t, n, r), float("nan"), device="cuda")
+    res.encode_into(x.cuda(), out)
+    assert float(out.abs().max()) > 1.5                     # the state does leave the unit interval
+    check(out, x, res, "tanh", sorted({0, 1, 15, 16, n // 2, n - 2, n - 1}))

@@ -125,19 +125,19 @@ __device__ __forceinline__ f32x4 bf3_mfma(const u32x4& w, const u32x4& v, f32x4 
 constexpr float kSj16StateScale = 16384.f;
 // two scaled fp16 pieces of a pair of values (v_fma_mixlo / mixhi_f16: fp32 fma rounded once to fp16 into one half of
 // the destination; the remainder of an 11-bit rounding of a 24-bit value is exact in the fma)
+// (the low-half instruction leaves the other half of its destination alone and the high-half one then writes it: the
+// destination needs no initial value -- "=v", not a zeroed "+v")
 __device__ __forceinline__ void sj16_split2(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
-    hi = 0; lo = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "v"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "v"(s), "v"(hi));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "v"(s), "v"(hi));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "v"(s), "v"(hi));
 }
 // the same with the (wave-uniform) scale in a scalar register
 __device__ __forceinline__ void sj16_split2s(float v0, float v1, float s, unsigned& hi, unsigned& lo) {
-    hi = 0; lo = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v0), "s"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(v0), "s"(s));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(v1), "s"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v0), "s"(s), "v"(hi));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(lo) : "v"(v0), "s"(s), "v"(hi));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(v1), "s"(s), "v"(hi));
 }
 __device__ __forceinline__ f32x4 sj16_mfma(const u32x4& w, const u32x4& v, f32x4 acc) {
@@ -346,9 +346,7 @@ __global__ __launch_bounds__(PAIR ? 768 : 1024, PAIR ? 3 : 4) void reservoir_lay
                     if (bf3_abl(4)) {
                     } else if (H16 || a.act == SGP_ACT_TANH) {
 #pragma unroll
-                        for (int jt = 0; jt < JT; ++jt)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) acc[g][jt][r] = tanh_r(acc[g][jt][r]);
+                        for (int jt = 0; jt < JT; ++jt) acc[g][jt] = tanh_r4(acc[g][jt]);
                     } else if (a.act == SGP_ACT_RELU) {
 #pragma unroll
                         for (int jt = 0; jt < JT; ++jt)

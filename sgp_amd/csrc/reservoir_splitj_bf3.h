@@ -46,7 +46,8 @@ __host__ __device__ constexpr long long sjbf3_lds_bytes(int JT, int NKX) {
 }
 
 // experiment switches (build with -DSGP_SJ_ABL=bits): 1 no result stores, 2 wave 0's row wait counts its stores too,
-// 4 no row wait at all (wrong results), 8 no activation, 16 no piece exchange (wrong results), 32 no MFMAs
+// 4 no row wait at all (wrong results), 8 no activation, 16 no piece exchange (wrong results), 32 no MFMAs,
+// 128 no row requests inside the time loop (wrong results)
 #ifndef SGP_SJ_ABL
 #define SGP_SJ_ABL 0
 #endif
@@ -250,7 +251,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
 
     for (int t = 0; t < a.T; ++t) {
         if (t > 0 && !sj_abl(1)) store_h(t - 1, hown);
-        if (wave == 0) dma_next();                       // the row of step t + PFD - 1, into the slot consumed one step ago
+        if (wave == 0 && !sj_abl(128)) dma_next();       // the row of step t + PFD - 1, into the slot consumed one step ago
         // B operands: the state pieces of step t - 1 (all tiles), leading pieces of every k-block first (the first round
         // of products needs exactly those)
         u32x4 V[KBH][3];
@@ -271,7 +272,11 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
         // NCHN chains per tile, the k-blocks dealt to them in turn: a chain's next MFMA is NCHN x JW issues (>= 34 cycles) behind
         // the one it waits for (29), and the end needs NCHN - 1 adds per tile instead of one per k-block -- with one chain
         // per k-block the accumulators' zeroing, read-out (v_accvgpr) and adds were 100 of the step's 508 instructions.
+#ifdef SGP_SJ_NCHN
+        constexpr int NCHN = SGP_SJ_NCHN < KBH ? SGP_SJ_NCHN : KBH;
+#else
         constexpr int NCHN = JW == 1 ? (KBH < 3 ? KBH : 3) : 2;
+#endif
         f32x4 pre[JW];
         auto finish = [&](int w) {                       // leak, publish the pieces of tile w
             f32x4 hn;
@@ -317,8 +322,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
                     f32x4 rec = acc[w][0];
 #pragma unroll
                     for (int c = 1; c < NCHN; ++c) rec += acc[w][c];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pre[w][r] = fmaf(rec[r], rsc[w][r], xsum[w][r]);
+                    pre[w] = __builtin_elementwise_fma(rec, rsc[w], xsum[w]);
                 } else {
                     pre[w] = xsum[w];
 #pragma unroll
@@ -327,9 +331,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
             }
             if (act == SGP_ACT_TANH && !sj_abl(8)) {
 #pragma unroll
-                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) pre[w][r] = tanh_r(pre[w][r]);
+                for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w) pre[w] = tanh_r4(pre[w]);
             } else if (act == SGP_ACT_RELU) {
 #pragma unroll
                 for (int w = TILEWISE ? w0 : 0; w < (TILEWISE ? w0 + 1 : JW); ++w)

@@ -47,7 +47,7 @@ __host__ __device__ constexpr long long sjbf3_lds_bytes(int JT, int NKX) {
 
 // experiment switches (build with -DSGP_SJ_ABL=bits): 1 no result stores, 2 wave 0's row wait counts its stores too,
 // 4 no row wait at all (wrong results), 8 no activation, 16 no piece exchange (wrong results), 32 no MFMAs,
-// 128 no row requests inside the time loop (wrong results)
+// 128 no row requests inside the time loop (wrong results); -DSGP_SJ_NCHN=n: accumulation chains per tile
 #ifndef SGP_SJ_ABL
 #define SGP_SJ_ABL 0
 #endif

@@ -198,14 +198,16 @@ __device__ __forceinline__ void wait_vm_n(int n) {       // n is wave-uniform, 0
 // (v_fma_mixlo / mixhi_f16: fp32 fma of (fp32 v, fp32 s, fp16 half of a register), rounded once to fp16 into the low
 // / high half of the destination) -- the remainder of an 11-bit rounding of a 24-bit value is exact in the fma.
 __device__ __forceinline__ void split4(const f32x4 v, const f32x4 s, uint2& hi, uint2& lo) {
-    unsigned h01 = 0, h23 = 0, l01 = 0, l23 = 0;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v[0]), "v"(s[0]));
+    // (the low-half instruction leaves the other half of its destination alone and the high-half one then writes it: no
+    // zeroed destinations -- four v_mov per piece less)
+    unsigned h01, h23, l01, l23;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h01) : "v"(v[0]), "v"(s[0]));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h01) : "v"(v[1]), "v"(s[1]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v[2]), "v"(s[2]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h23) : "v"(v[2]), "v"(s[2]));
     asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h23) : "v"(v[3]), "v"(s[3]));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v[0]), "v"(s[0]), "v"(h01));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l01) : "v"(v[0]), "v"(s[0]), "v"(h01));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l01) : "v"(v[1]), "v"(s[1]), "v"(h01));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v[2]), "v"(s[2]), "v"(h23));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=&v"(l23) : "v"(v[2]), "v"(s[2]), "v"(h23));
     asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l23) : "v"(v[3]), "v"(s[3]), "v"(h23));
     hi.x = h01; hi.y = h23; lo.x = l01; lo.y = l23;
 }

@@ -42,10 +42,12 @@
 extern "C" {
 #endif
 
-/* 2 (round 5): sgp_spmm_split_f32 takes per-column scale tables and a per-row plan array; sgp_col_stats_f32,
+/* 3 (round 6): the launch predicate became the explicit trailing (pred, run_if) pair of every sgp_spmm_*_f32 entry
+ * (sgp_launch_predicate removed); host-side planner sgp_split_plan_deal / sgp_split_plan_fill added.
+ * 2 (round 5): sgp_spmm_split_f32 takes per-column scale tables and a per-row plan array; sgp_col_stats_f32,
  * sgp_split_prepare_f32, sgp_launch_predicate added; round 4 had already removed sgp_spmm_mfma / pipe / blk_*, widened
  * sgp_spmm_colblock_f32 by the halo arguments and grown sgp_reservoir_workspace_bytes (bf16-piece fragments). */
-#define SGP_ABI_VERSION 2
+#define SGP_ABI_VERSION 3
 
 #define SGP_EINVAL   (-1)  /* bad size / null pointer / misaligned stride */
 #define SGP_EUNSUP   (-2)  /* shape outside what the kernels are built for */
@@ -88,7 +90,7 @@ int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
                      int32_t n_own,
                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream);
+                     const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 
 /* LDS-staged variant for graphs with locality.  Rows are grouped into tiles of at most
  * `tile_rows` consecutive rows (tile k = rows tile_row_ptr[k] .. tile_row_ptr[k+1]); for
@@ -115,7 +117,7 @@ int sgp_spmm_tiled_f32(const int32_t* tile_row_ptr, const int32_t* uptr, const i
                        int32_t n_own,
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                       sgp_stream_t stream);
+                       const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 /* Row-group kernel on the fp32 matrix cores, exact fp32 (lib/sgp_preprocessing.py:200-203, `x = adj @ x` per hop).
  * Tiles of at most 64 rows and their distinct-column lists as above; every tile is cut into 16 groups of 4
  * rows (slots 4g .. 4g+3 of the tile, see rowmap).  A group's sorted column union is dealt round-robin to 4
@@ -151,7 +153,7 @@ int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
                      int32_t n_own,
                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream);
+                     const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 int32_t sgp_spmm_res_max_union(void);
 int32_t sgp_spmm_res_max_quads(void);
 int sgp_spmm_res_tune(int32_t cfg);
@@ -182,7 +184,7 @@ int sgp_spmm_mix_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
                      int32_t n_own,
                      float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream);
+                     const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 int32_t sgp_spmm_mix_max_union(void);
 int32_t sgp_spmm_mix_max_dense(int32_t halo);
 
@@ -193,12 +195,13 @@ int32_t sgp_spmm_mix_max_dense(int32_t halo);
 int sgp_abs_max_f32(const float* X, int64_t x_row_stride, int64_t x_batch_stride,
                     int32_t n_rows, int32_t batch, int32_t feat, float* out, sgp_stream_t stream);
 
-/* Launch predicate: the NEXT hop launch (sgp_spmm_*_f32) of the calling host thread runs only if *flag == run_if
- * when its kernel starts on the stream, and is a no-op otherwise; the setting is consumed by that one call.  This is
- * how a hop chooses between the split-fp16 kernel and the exact-fp32 kernels ON THE DEVICE: sgp_split_prepare_f32
- * writes the flag, the caller enqueues sgp_spmm_split_f32 with run_if = 1 and its exact kernel with run_if = 0
- * (no host round trip, legal under stream capture).  flag = NULL clears it. */
-int sgp_launch_predicate(const int32_t* flag, int32_t run_if);
+/* Launch predicate of the hop entries (the trailing `pred, run_if` pair of every sgp_spmm_*_f32): with pred != NULL (a
+ * DEVICE word) the launch runs only if *pred == run_if when its kernel starts on the stream, and is a no-op otherwise
+ * (every workgroup exits at its first instruction).  This is how a hop chooses between the split-fp16 kernel and the
+ * exact-fp32 kernels ON THE DEVICE: sgp_split_prepare_f32 writes the flag, the caller enqueues sgp_spmm_split_f32 with
+ * run_if = 1 and its exact kernel with run_if = 0 behind it (no host round trip, legal under stream capture).
+ * pred = NULL: unconditional.  (ABI 2 carried this as thread-local state set by sgp_launch_predicate(); ABI 3 made it
+ * an argument so that nothing armed by one call can reach another.) */
 
 /* Per-column statistics of a strided [batch, n_rows, feat] view over the steps 0, t_stride, 2 t_stride, ... and the rows
  * 0, r_stride, 2 r_stride, ...: stats[0 : feat] = max |x[:, c]| (bit pattern of the float; NaN / inf win),
@@ -254,12 +257,33 @@ int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* 
                        const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                        float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                       const float* x_tab, int32_t accumulate, int32_t t_chunk, sgp_stream_t stream);
+                       const float* x_tab, int32_t accumulate, int32_t t_chunk, const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 int32_t sgp_spmm_split_chunks(void);
 int32_t sgp_spmm_split_max_union(void);
 int32_t sgp_spmm_split_waves(void);
 int32_t sgp_spmm_split_rows_per_wave(void);
 int32_t sgp_spmm_split_max_feat(void);
+
+/* Host-side planner of sgp_spmm_split_f32 (csrc/plan_split.hip; HOST pointers, no GPU needed; the encoder builds the
+ * plan once per graph in front of `x = adj @ x`, lib/sgp_preprocessing.py:188-203).
+ * sgp_split_plan_deal: rows -- in `order` (n_order entries) or 0 .. n_rows - 1 when order = NULL -- are dealt greedily to
+ * waves of at most rows_per_wave rows touching at most 32 * chunks distinct columns, waves to tiles of at most `waves`
+ * waves touching at most max_union distinct columns.  Writes wave_of_row / slot_of_row [n_rows] (-1 for rows outside
+ * the order) and tile_of_wave / rows_of_wave (capacity n_rows); returns the number of waves, -2 when a single row
+ * exceeds a wave's budget (no one-pass plan), -1 on a bad argument.
+ * sgp_split_plan_fill: the kernel's arrays (formats: sgp_spmm_split_f32 above) for that deal, tiles in parallel on
+ * `threads` host threads (0 = all); stats[8] = tiles, waves, rows per wave, rows per tile, staged rows per result row,
+ * chunk fill, largest staged-row count, ||A||_inf. */
+int64_t sgp_split_plan_deal(const int64_t* rowptr, const int64_t* col, int64_t n_rows, int64_t n_cols,
+                            const int64_t* order, int64_t n_order,
+                            int32_t waves, int32_t chunks, int32_t max_union, int32_t rows_per_wave,
+                            int64_t* wave_of_row, int64_t* slot_of_row, int64_t* tile_of_wave, int64_t* rows_of_wave);
+int sgp_split_plan_fill(const int64_t* rowptr, const int64_t* col, const float* val, int64_t n_rows, int64_t n_cols,
+                        const int64_t* wave_of_row, const int64_t* slot_of_row, const int64_t* tile_of_wave,
+                        const int64_t* rows_of_wave, int64_t n_waves, int64_t n_tiles,
+                        int32_t waves, int32_t chunks, int32_t max_union,
+                        int32_t* hdr, int32_t* rowid, int32_t* ucol, void* afr, int32_t* adr, float* rinv,
+                        double* stats, int32_t threads);
 
 /* Column-blocked hop for graphs without locality (lib/sgp_preprocessing.py:202, `x = adj @ x`; plan:
  * sgp_amd/colblock.py).  The columns are cut into n_blocks blocks of consecutive columns whose source
@@ -280,7 +304,7 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
                           const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                           float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                           int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                          sgp_stream_t stream);
+                          const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 int32_t sgp_spmm_colblock_rows_cap(void);
 int32_t sgp_spmm_colblock_round_pad(void);
 

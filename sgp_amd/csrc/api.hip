@@ -64,14 +64,9 @@ SideLane* side_lane() {
     }
     return &lanes[dev];
 }
-static thread_local Predicate g_pred = {nullptr, 0};
-Predicate take_predicate() { Predicate p = g_pred; g_pred = Predicate{nullptr, 0}; return p; }
-void set_predicate(const int* flag, int want) { g_pred = Predicate{flag, want}; }
 }  // namespace sgp
 
 extern "C" {
-
-int sgp_launch_predicate(const int32_t* flag, int32_t run_if) { sgp::set_predicate(flag, run_if); return 0; }
 
 int sgp_abi_version(void) { return SGP_ABI_VERSION; }
 const char* sgp_last_error(void) { return sgp::err_buf(); }

@@ -36,12 +36,10 @@ struct SideLane {
 SideLane* side_lane();
 
 
-// Launch predicate (sgp_launch_predicate): the NEXT hop launch of this host thread runs only if *flag == want when the
-// kernel starts (device-side choice between the split-fp16 hop and the exact kernels, no host round trip).  Every
-// hop launcher takes it -- also on its early-return paths -- so that it never outlives the call it was set for.
+// Launch predicate (the trailing `pred, run_if` pair of the hop entries, include/sgp_amd.h): the launch runs only if
+// *flag == want when the kernel starts (device-side choice between the split-fp16 hop and the exact kernels, no host
+// round trip); flag == nullptr: unconditional.
 struct Predicate { const int* flag; int want; };
-Predicate take_predicate();
-void set_predicate(const int* flag, int want);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -435,8 +435,8 @@ int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
                      const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
                      float* Y, int64_t yrs, int64_t ybs,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream) {
-    const sgp::Predicate pr = sgp::take_predicate();
+                     const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    const sgp::Predicate pr{pred, run_if};
     SGP_REQUIRE(rowptr && col && val && X && Y, "sgp_spmm_csr_f32: null pointer");
     SGP_REQUIRE(n_rows >= 0 && n_cols >= 0 && batch >= 0 && feat >= 0, "sgp_spmm_csr_f32: negative size");
     SGP_REQUIRE(Xh != nullptr || n_own >= n_cols, "sgp_spmm_csr_f32: n_own < n_cols needs X_halo");
@@ -475,8 +475,8 @@ int sgp_spmm_tiled_f32(const int32_t* trow, const int32_t* uptr, const int32_t* 
                        const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
                        float* Y, int64_t yrs, int64_t ybs,
                        int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                       sgp_stream_t stream) {
-    const sgp::Predicate pr = sgp::take_predicate();
+                       const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    const sgp::Predicate pr{pred, run_if};
     SGP_REQUIRE(trow && uptr && ucol && erow && ecol && eval && X && Y, "sgp_spmm_tiled_f32: null pointer");
     SGP_REQUIRE(tile_rows > 0 && n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 &&
                 max_row_edges >= 0 && max_row_edges % 16 == 0, "sgp_spmm_tiled_f32: bad size");

@@ -154,8 +154,8 @@ int sgp_spmm_colblock_f32(const int32_t* plan, const int32_t* segptr, const int3
                           const float* X_halo, int64_t xhrs, int64_t xhbs, int32_t n_own,
                           float* Y, int64_t yrs, int64_t ybs,
                           int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                          sgp_stream_t stream) {
-    const sgp::Predicate pr = sgp::take_predicate();
+                          const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    const sgp::Predicate pr{pred, run_if};
     SGP_REQUIRE(plan && segptr && wg_row0 && X && Y, "sgp_spmm_colblock_f32: null pointer");
     SGP_REQUIRE(n_wg >= 0 && n_blocks >= 0 && n_rows >= 0 && n_cols >= 0 && batch >= 0 && feat >= 0,
                 "sgp_spmm_colblock_f32: bad size");

@@ -484,8 +484,8 @@ int sgp_spmm_res_f32(const int32_t* uptr, const int32_t* ucol, const int32_t* us
                      const float* Xh, int64_t xhrs, int64_t xhbs, int32_t n_own,
                      float* Y, int64_t yrs, int64_t ybs,
                      int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                     sgp_stream_t stream) {
-    const sgp::Predicate pr = sgp::take_predicate();
+                     const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    const sgp::Predicate pr{pred, run_if};
     SGP_REQUIRE(uptr && ucol && usplit && gptr && gsup && gidx && gw && rowmap && X && Y,
                 "sgp_spmm_res_f32: null pointer");
     SGP_REQUIRE(n_tiles >= 0 && n_rows >= 0 && batch >= 0 && max_union >= 0 && max_tile_quads >= 0,

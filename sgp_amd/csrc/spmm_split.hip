@@ -15,7 +15,7 @@
 // bound at 2^13 .. 2^14 a value keeps 22 bits down to 2^-16 of the bound; below that the low piece is an fp16
 // subnormal and the error becomes ABSOLUTE, <= 2^-38 x the column's bound -- which is why the default dispatch
 // (sgp_split_prepare_f32) admits this kernel only where that is below 2^-22 of the column's RMS, and sends
-// everything else to the exact-fp32 kernels (launch predicate, sgp_launch_predicate).
+// everything else to the exact-fp32 kernels (launch predicate: the entry's `pred, run_if` pair).
 //
 // Structure (plan: sgp_amd/splitplan.py):
 //   * a workgroup of NW = 16 waves owns a tile of up to 16 x 16 rows for a chunk of time steps; wave w owns up to 16
@@ -118,7 +118,7 @@ struct SplitArgs {
     float* Y; long long yrs, ybs;
     int batch, nslice, t_chunk;
     const float* xtab;                       // [2][16 nslice]: per-column scale, then its inverse
-    const int* pred; int pred_want;          // launch predicate (sgp_launch_predicate): run only if *pred == pred_want
+    const int* pred; int pred_want;          // launch predicate (`pred, run_if` of the entry): run only if *pred == pred_want
     unsigned long long* dbg;                 // mode 256: per-wave s_memtime stamps of workgroup 0
     int mode;                                // ablations (SGP_TUNE=split_abl=..): 1 no loads, 2 no MFMAs, 4 no stores, 8 no conversion, 16 all tiles of an XCD stage the same rows, 32 unpaired stores, 64 all loads hit the L2
 };
@@ -471,8 +471,8 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
                                   const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
                                   float* Y, int64_t y_row_stride, int64_t y_batch_stride,
                                   int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
-                                  const float* x_tab, int32_t accumulate, int32_t t_chunk, sgp_stream_t stream) {
-    const sgp::Predicate pr = sgp::take_predicate();
+                                  const float* x_tab, int32_t accumulate, int32_t t_chunk, const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    const sgp::Predicate pr{pred, run_if};
     SGP_REQUIRE(n_tiles >= 0 && batch >= 0 && n_rows >= 0 && n_cols >= 0, "spmm_split: negative size");
     if (n_tiles == 0 || batch == 0 || n_rows == 0) return 0;
     SGP_REQUIRE(hdr && rowid && ucol && afr && adr && rinv && X && Y && x_tab, "spmm_split: null pointer");

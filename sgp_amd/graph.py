@@ -371,11 +371,7 @@ class ShiftOperator:
             elif force == "split":
                 raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")
             plan = self.tile_plan(x.shape[2], x.device, tall=True) if fits32 else None
-        try:
-            name = self._propagate_exact(x, y, force, halo, plan, fits32, pending)
-        finally:
-            if pending is not None:
-                hip.launch_predicate(None, 0)          # (consumed by the launch; cleared here if the dispatch raised)
+        name = self._propagate_exact(x, y, force, halo, plan, fits32, pending)
         if pending is not None:
             self.last_kernel, self.last_exact_kernel, self.last_split_flag = "spmm_split", name, pending
         else:
@@ -400,9 +396,7 @@ class ShiftOperator:
         from . import hip
 
         def launch(fn, *args):
-            if pending is not None:
-                hip.launch_predicate(pending, 0)
-            fn(*args)
+            fn(*args, pred=None if pending is None else (pending, 0))
 
         # 2. exact fp32 on the matrix cores: the mixed dense (16x16x4) / sparse (4x4x1) kernel where the planner
         # finds enough shared columns (k-NN-like graphs), else the register-resident row-group kernel

@@ -30,19 +30,19 @@ SIGNATURES = {
                                         c_p, c_i64, c_i64,
                                         c_p, c_i64, c_i64, c_i32,
                                         c_p, c_i64, c_i64,
-                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+                                        c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_spmm_tiled_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p,
                                           c_i32, c_i32, c_i32, c_i32,
                                           c_p, c_i64, c_i64,
                                           c_p, c_i64, c_i64, c_i32,
                                           c_p, c_i64, c_i64,
-                                          c_i32, c_i32, c_i32, c_i32, c_p]),
+                                          c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_spmm_res_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                         c_i32, c_i32, c_i32,
                                         c_p, c_i64, c_i64,
                                         c_p, c_i64, c_i64, c_i32,
                                         c_p, c_i64, c_i64,
-                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+                                        c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_spmm_res_max_union": (c_i32, []),
     "sgp_spmm_res_max_quads": (c_i32, []),
     "sgp_spmm_res_tune": (ctypes.c_int, [c_i32]),
@@ -52,7 +52,7 @@ SIGNATURES = {
                                         c_p, c_i64, c_i64,
                                         c_p, c_i64, c_i64, c_i32,
                                         c_p, c_i64, c_i64,
-                                        c_i32, c_i32, c_i32, c_i32, c_p]),
+                                        c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_spmm_mix_max_union": (c_i32, []),
     "sgp_spmm_mix_max_dense": (c_i32, [c_i32]),
     "sgp_spmm_tiled_max_union": (c_i32, [c_i32]),
@@ -111,8 +111,7 @@ SIGNATURES = {
     "sgp_abs_max_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_p, c_p]),
     "sgp_spmm_split_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64,
                                           c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
-                                          c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p]),
-    "sgp_launch_predicate": (ctypes.c_int, [c_p, c_i32]),
+                                          c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_col_stats_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     "sgp_split_prepare_f32": (ctypes.c_int, [c_p, c_f64, c_f64, c_i32, c_p, c_f32, c_f32, c_i32, c_p, c_p, c_p, c_p]),
     "sgp_spmm_split_chunks": (c_i32, []),
@@ -120,9 +119,12 @@ SIGNATURES = {
     "sgp_spmm_split_waves": (c_i32, []),
     "sgp_spmm_split_rows_per_wave": (c_i32, []),
     "sgp_spmm_split_max_feat": (c_i32, []),
+    "sgp_split_plan_deal": (c_i64, [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_i32, c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p]),
+    "sgp_split_plan_fill": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64,
+                                           c_i32, c_i32, c_i32, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i32]),
     "sgp_spmm_colblock_f32": (ctypes.c_int, [c_p, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_i64,
                                              c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
-                                             c_i32, c_i32, c_i32, c_i32, c_p]),
+                                             c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_spmm_colblock_rows_cap": (c_i32, []),
     "sgp_spmm_colblock_round_pad": (c_i32, []),
     "sgp_event_create": (ctypes.c_int, [ctypes.POINTER(c_p)]),
@@ -142,8 +144,9 @@ def build(jobs=8, verbose=False, asan=False):
     builds ``csrc/build_asan/libsgp_amd_asan.so`` -- the host halves under AddressSanitizer -- which
     ``tests/test_abi.py::test_host_asan_build`` drives (argument checks of every entry point, planner
     output through the hop kernels' launch arithmetic)."""
-    out = subprocess.run(["make", "-C", _CSRC, f"-j{jobs}"] + (["libsgp_amd.so", "asan"] if asan else []),
-                         capture_output=True, text=True)
+    out = subprocess.run(["make", "-C", _CSRC, f"-j{jobs}"], capture_output=True, text=True)
+    if asan and out.returncode == 0:
+        out = subprocess.run(["make", "-C", _CSRC, "-f", "Makefile.asan", f"-j{jobs}"], capture_output=True, text=True)
     if verbose or out.returncode:
         print(out.stdout[-4000:])
         print(out.stderr[-4000:])
@@ -165,7 +168,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
-    if lib.sgp_abi_version() != 2:
+    if lib.sgp_abi_version() != 3:
         raise RuntimeError("libsgp_amd.so ABI version mismatch; rebuild it")
     _lib = lib
     return lib
@@ -264,7 +267,7 @@ MAX_GRID_BATCH = 65535
 
 # ---------------------------------------------------------------- SpMM
 @_on_device
-def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
+def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None, pred=None):
     """y[b, i, :] = sum_e val[e] x[b, col[e], :] (generic CSR kernel)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
@@ -289,11 +292,11 @@ def spmm_csr(rowptr, col, val, x, y, halo=None, n_own=None):
             xp + 4 * b0 * xbs, xrs, xbs,
             (hp + 4 * b0 * hbs) if hp else None, hrs, hbs, n_own,
             yp + 4 * b0 * ybs, yrs, ybs,
-            n_rows, n_cols, nb, D, _stream(x)), "sgp_spmm_csr_f32")
+            n_rows, n_cols, nb, D, *_pred(pred), _stream(x)), "sgp_spmm_csr_f32")
 
 
 @_on_device
-def spmm_tiled(plan, x, y, halo=None, n_own=None):
+def spmm_tiled(plan, x, y, halo=None, n_own=None, pred=None):
     """Same product through the LDS-staged kernel; ``plan`` from graph.TilePlan.to(device)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
@@ -309,11 +312,11 @@ def spmm_tiled(plan, x, y, halo=None, n_own=None):
         plan.tile_rows, plan.n_tiles, plan.max_union, plan.max_row_edges,
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_tiled_f32")
+        x.shape[0], x.shape[2], *_pred(pred), _stream(x)), "sgp_spmm_tiled_f32")
 
 
 @_on_device
-def spmm_res(plan, x, y, halo=None, n_own=None):
+def spmm_res(plan, x, y, halo=None, n_own=None, pred=None):
     """Register-resident two-phase row-group product, exact fp32 (plan: ``TilePlan.pipe``)."""
     lib = require_gpu()
     xp, xrs, xbs = _view3(x, "x")
@@ -331,11 +334,11 @@ def spmm_res(plan, x, y, halo=None, n_own=None):
         plan.n_tiles, ps["max_union"], ps["max_tile_quads"],
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_res_f32")
+        x.shape[0], x.shape[2], *_pred(pred), _stream(x)), "sgp_spmm_res_f32")
 
 
 @_on_device
-def spmm_mix(plan, x, y, halo=None, n_own=None):
+def spmm_mix(plan, x, y, halo=None, n_own=None, pred=None):
     """Mixed dense (16x16x4) / sparse (4x4x1) row-group product (plan: sgp_amd.mixplan.MixPlan on the
     device of ``x``)."""
     lib = require_gpu()
@@ -353,7 +356,7 @@ def spmm_mix(plan, x, y, halo=None, n_own=None):
         plan.n_tiles, plan.max_union, plan.max_dense,
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs,
         plan.n_rows, x.shape[1] + (halo.shape[1] if halo is not None else 0),
-        x.shape[0], x.shape[2], _stream(x)), "sgp_spmm_mix_f32")
+        x.shape[0], x.shape[2], *_pred(pred), _stream(x)), "sgp_spmm_mix_f32")
 
 
 @_on_device
@@ -384,10 +387,15 @@ class SplitProfile:
         self.tab, self.flag, self.bound_out = tab, flag, bound_out
 
 
-def launch_predicate(flag, run_if):
-    """The next hop launch of this thread runs only if ``flag[0] == run_if`` on the device (None clears)."""
-    lib = require_gpu()
-    _check(lib.sgp_launch_predicate(None if flag is None else flag.data_ptr(), int(run_if)), "sgp_launch_predicate")
+def _pred(pred):
+    """``pred`` of the hop bindings: None (unconditional) or ``(flag, run_if)`` -- the launch runs only if the DEVICE
+    word ``flag[0] == run_if`` when its kernel starts (include/sgp_amd.h, "Launch predicate")."""
+    if pred is None:
+        return None, 0
+    flag, run_if = pred
+    if not (torch.is_tensor(flag) and flag.is_cuda and flag.dtype == torch.int32 and flag.numel() >= 1):
+        raise ValueError("pred: expected (int32 CUDA tensor, run_if)")
+    return flag.data_ptr(), int(run_if)
 
 
 @_on_device
@@ -469,19 +477,18 @@ def spmm_split(plan, x, y, profile, t_chunk=0, halo=None, n_own=None, predicated
     if not isinstance(profile, SplitProfile):
         profile = split_profile(x, halo, profile, guard=False)
     plans = plan if isinstance(plan, (list, tuple)) else [plan]
+    pr = _pred((profile.flag, 1) if predicated else None)
     for p in plans:                                   # (several passes: an operator whose long rows were cut into column segments)
-        if predicated:
-            launch_predicate(profile.flag, 1)
         _check(lib.sgp_spmm_split_f32(
             p.hdr.data_ptr(), p.rowid.data_ptr(), p.ucol.data_ptr(), p.afr.data_ptr(), p.adr.data_ptr(),
             p.rinv.data_ptr(), p.n_tiles,
             xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, p.n_rows, p.n_cols, x.shape[0], x.shape[2],
-            profile.tab.data_ptr(), int(p.accumulate), t_chunk, _stream(x)), "sgp_spmm_split_f32")
+            profile.tab.data_ptr(), int(p.accumulate), t_chunk, *pr, _stream(x)), "sgp_spmm_split_f32")
     return profile
 
 
 @_on_device
-def spmm_colblock(plan, x, y, halo=None, n_own=None):
+def spmm_colblock(plan, x, y, halo=None, n_own=None, pred=None):
     """Column-blocked hop for graphs without locality (plan: sgp_amd.colblock.ColBlockPlan on the device
     of ``x``)."""
     lib = require_gpu()
@@ -494,8 +501,8 @@ def spmm_colblock(plan, x, y, halo=None, n_own=None):
         hp, hrs, hbs, n_own = None, 0, 0, 0
     _check(lib.sgp_spmm_colblock_f32(
         plan.entries.data_ptr(), plan.segptr.data_ptr(), plan.wg_row0.data_ptr(), plan.n_wg, plan.n_blocks,
-        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], _stream(x)),
-        "sgp_spmm_colblock_f32")
+        xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], *_pred(pred),
+        _stream(x)), "sgp_spmm_colblock_f32")
 
 
 def tiled_limits(feat):

@@ -142,10 +142,58 @@ def _bank_aware_slots(w_of_key, pos_of_key, stage, n_chunks_total, chunks):
     return chunk * 32 + slot
 
 
-def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None, rows_per_wave=16):
+def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None, rows_per_wave=16,
+                     threads=0):
     """``order``: optional sequence of rows (a locality order of the graph, or the subset of rows a later pass of a
     long-row operator touches): rows are dealt to waves in that sequence -- rows outside it get no slot -- while the plan
-    keeps addressing rows and columns by their ORIGINAL ids, so no tensor is ever permuted."""
+    keeps addressing rows and columns by their ORIGINAL ids, so no tensor is ever permuted.
+
+    The work is done by the library's host-side planner (``csrc/plan_split.hip``: ``sgp_split_plan_deal`` /
+    ``sgp_split_plan_fill``, all cores; no GPU needed); ``build_split_plan_numpy`` below is the same algorithm in numpy,
+    kept as its cross-check (tests/test_splitplan.py holds the two to the same bytes) -- 2 s instead of 23 s on the
+    target graph."""
+    import ctypes
+    from . import hip
+    lib = hip.load()
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int64)
+    val = np.ascontiguousarray(val, dtype=np.float32)
+    if n_rows == 0 or col.size == 0 or not np.isfinite(val).all():
+        return None
+    assert rows_per_wave == 16 and rowptr.size >= n_rows + 1
+    if col.min() < 0 or col.max() >= n_cols:
+        raise ValueError("column index out of range")
+    seq = None if order is None else np.ascontiguousarray(order, dtype=np.int64)
+    ptr = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    wave_of_row, slot_of_row = np.empty(n_rows, dtype=np.int64), np.empty(n_rows, dtype=np.int64)
+    tile_of_wave, rows = np.empty(n_rows, dtype=np.int64), np.empty(n_rows, dtype=np.int64)
+    n_waves = lib.sgp_split_plan_deal(ptr(rowptr), ptr(col), n_rows, n_cols, None if seq is None else ptr(seq),
+                                      0 if seq is None else seq.size, waves, chunks, max_union, rows_per_wave,
+                                      ptr(wave_of_row), ptr(slot_of_row), ptr(tile_of_wave), ptr(rows))
+    if n_waves == -2 or n_waves == 0:
+        return None                                   # a row beyond a wave's column budget / nothing dealt
+    if n_waves < 0:
+        raise RuntimeError("sgp_split_plan_deal: " + lib.sgp_last_error().decode())
+    tile_of_wave, rows = tile_of_wave[:n_waves], rows[:n_waves]
+    n_tiles = int(tile_of_wave[-1]) + 1
+    hdr = torch.empty((n_tiles, 64), dtype=torch.int32)
+    rowid = torch.empty((n_tiles, waves, rows_per_wave), dtype=torch.int32)
+    ucol = torch.empty((n_tiles, max_union), dtype=torch.int32)
+    afr = torch.empty((n_tiles, waves, chunks, 2, 64, 8), dtype=torch.float16)
+    adr = torch.empty((n_tiles, waves, chunks, 64), dtype=torch.int32)
+    rinv = torch.empty((n_tiles, waves, 16), dtype=torch.float32)
+    st = np.zeros(8, dtype=np.float64)
+    hip._check(lib.sgp_split_plan_fill(ptr(rowptr), ptr(col), ptr(val), n_rows, n_cols, ptr(wave_of_row), ptr(slot_of_row),
+                                       ptr(tile_of_wave), ptr(rows), n_waves, n_tiles, waves, chunks, max_union,
+                                       hdr.data_ptr(), rowid.data_ptr(), ucol.data_ptr(), afr.data_ptr(), adr.data_ptr(),
+                                       rinv.data_ptr(), ptr(st), int(threads)), "sgp_split_plan_fill")
+    stats = dict(tiles=n_tiles, waves=int(n_waves), rows_per_wave=float(st[2]), rows_per_tile=float(st[3]),
+                 staged_per_row=float(st[4]), chunk_fill=float(st[5]), max_union=int(st[6]))
+    return SplitPlan(hdr, rowid, ucol, afr, adr, rinv, n_tiles, n_rows, n_cols, float(st[7]), stats)
+
+
+def build_split_plan_numpy(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_union=768, order=None, rows_per_wave=16):
+    """The planner in numpy: the reference the native planner is tested against (same arrays, byte for byte)."""
     rowptr = np.asarray(rowptr, dtype=np.int64)
     col = np.asarray(col, dtype=np.int64)
     val = np.asarray(val, dtype=np.float32)
@@ -162,6 +210,10 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_u
     w_in_tile = np.arange(n_waves) - first_wave_of_tile[tile_of_wave]
 
     row_of_edge = np.repeat(np.arange(n_rows, dtype=np.int64), np.diff(rowptr[:n_rows + 1]))
+    rowsum = np.zeros(n_rows, dtype=np.float64)
+    np.add.at(rowsum, row_of_edge, np.abs(val.astype(np.float64)))
+    dealt = wave_of_row[row_of_edge] >= 0                # entries of rows outside ``order`` belong to no wave
+    row_of_edge, col, val = row_of_edge[dealt], col[dealt], val[dealt]
     e_wave = wave_of_row[row_of_edge]
     e_tile = tile_of_wave[e_wave]
     # staged position of every (tile, column)
@@ -172,6 +224,9 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_u
     stage_of_key = np.arange(tkey.size) - t_first[t_of_key]
     ucol = np.full((n_tiles, max_union), -1, dtype=np.int32)
     ucol[t_of_key, stage_of_key] = (tkey % n_cols).astype(np.int32)
+    empty = union == 0                                    # a tile of empty rows still stages one (finite) row: its padding reads
+    ucol[empty, 0] = 0
+    union = np.where(empty, 1, union)
     # position of every (wave, column) in the wave's column list
     wkey, winv = np.unique(e_wave * n_cols + col, return_inverse=True)
     w_of_key = wkey // n_cols
@@ -213,8 +268,9 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_u
     dense = np.zeros((n_waves, chunks, 64, 8), dtype=np.float32)         # [wave, chunk, lane, e], lane = slot + 16 (k / 8)
     np.add.at(dense, (e_wave, pos // 32, slot + 16 * (k // 8), k % 8), val)
     rmax = np.abs(dense).reshape(n_waves, chunks, 4, 16, 8).max(axis=(1, 2, 4))          # [wave, slot], after the duplicates were summed
-    with np.errstate(divide="ignore"):
-        e_row = np.where(rmax > 0, np.floor(np.log2(16384.0 / np.maximum(rmax, 1e-300))), 0.0)
+    with np.errstate(divide="ignore", over="ignore"):
+        q = np.float32(16384.0) / rmax                     # floor(log2(q)) by exponent extraction (exact)
+    e_row = np.where(rmax > 0, np.where(np.isinf(q), 126.0, np.frexp(np.where(np.isfinite(q), q, 1.0))[1] - 1.0), 0.0)
     e_row = np.clip(e_row, -126, 126)
     rscale = np.exp2(e_row).astype(np.float32)                           # [wave, slot]
     lane_scale = np.tile(rscale, (1, 4))                                 # lane = slot + 16 g
@@ -232,8 +288,6 @@ def build_split_plan(rowptr, col, val, n_rows, n_cols, waves=16, chunks=7, max_u
     all_rows = np.flatnonzero(wave_of_row >= 0)
     rowid[tile_of_wave[wave_of_row[all_rows]], w_in_tile[wave_of_row[all_rows]], slot_of_row[all_rows]] = all_rows
     hdr[:, 2 * waves] = union
-    rowsum = np.zeros(n_rows, dtype=np.float64)
-    np.add.at(rowsum, row_of_edge, np.abs(val.astype(np.float64)))
     n_dealt = max(1, int(all_rows.size))
     stats = dict(tiles=n_tiles, waves=n_waves, rows_per_wave=float(rows.mean()),
                  rows_per_tile=float(n_dealt / n_tiles), staged_per_row=float(union.sum() / n_dealt),

@@ -35,14 +35,14 @@ def test_binding_covers_header(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.sgp_abi_version() == 2
+    assert lib.sgp_abi_version() == 3
     assert lib.sgp_build_arch() == b"gfx950"
 
 
 def test_argument_errors_do_not_need_a_gpu(lib):
     # null pointers / bad sizes are rejected before anything touches the device
     rc = lib.sgp_spmm_csr_f32(None, None, None, None, 0, 0, None, 0, 0, 0, None, 0, 0,
-                              4, 4, 1, 4, None)
+                              4, 4, 1, 4, None, 0, None)
     assert rc == -1 and b"null pointer" in lib.sgp_last_error()
     assert lib.sgp_reservoir_workspace_bytes(3, 64) > 0
     assert lib.sgp_reservoir_workspace_bytes(3, 1000) == -1
@@ -66,8 +66,8 @@ ASAN_LIB = os.path.join(ROOT, "sgp_amd", "csrc", "build_asan", "libsgp_amd_asan.
 
 
 def test_host_asan_build():
-    """the host halves of the library under AddressSanitizer (`make -C sgp_amd/csrc
-    asan`; GPU ASan is not available on this pool).  Every entry point is driven through its
+    """the host halves of the library under AddressSanitizer (`make -C sgp_amd/csrc -f
+    Makefile.asan`; GPU ASan is not available on this pool).  Every entry point is driven through its
     argument checks -- null pointers, zero and negative sizes, unsupported shapes -- in a child
     process that preloads the ASan runtime; an ASan report aborts the child."""
     import glob
@@ -75,7 +75,7 @@ def test_host_asan_build():
     import sys
     # built (or brought up to date: make is incremental) on demand -- about 90 s on 8 cores after a source
     # change; a toolchain that cannot build it skips the test
-    r = subprocess.run(["make", "-C", os.path.join(ROOT, "sgp_amd", "csrc"), "-j8", "asan"],
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "sgp_amd", "csrc"), "-f", "Makefile.asan", "-j8"],
                        capture_output=True, text=True, timeout=1500)
     if r.returncode != 0 or not os.path.exists(ASAN_LIB):
         pytest.skip("ASan build failed here: " + r.stderr[-300:])
@@ -123,13 +123,13 @@ if not torch.cuda.is_available():
         rowptr, col, val = op.csr()
         rp32, c32 = rowptr.int(), col.int()
         rc = lib.sgp_spmm_csr_f32(P(rp32), P(c32), P(val), P(x), feat, n * feat, None, 0, 0, 0,
-                                  P(y), feat, n * feat, n, n, batch, feat, None)
+                                  P(y), feat, n * feat, n, n, batch, feat, None, 0, None)
         assert isinstance(rc, int) and rc != 0
         n_plans += 1
         if plan is None or plan.pipe is None:
             continue
         ps = plan.pipe
-        common = (P(x), feat, n * feat, None, 0, 0, 0, P(y), feat, n * feat, plan.n_rows, n, batch, feat, None)
+        common = (P(x), feat, n * feat, None, 0, 0, 0, P(y), feat, n * feat, plan.n_rows, n, batch, feat, None, 0, None)
         for fn in (lib.sgp_spmm_res_f32,):
             rc = fn(P(ps["uptr"]), P(ps["ucol"]), P(ps["usplit"]), P(ps["gptr"]), P(ps["gsup"]), P(ps["gidx"]),
                     P(ps["gw"]), P(ps["rowmap"]), plan.n_tiles, ps["max_union"], ps["max_tile_quads"], *common)
@@ -146,7 +146,7 @@ if not torch.cuda.is_available():
         if sp is not None and feat %% 16 == 0:
             tab = torch.ones(2, feat)
             rc = lib.sgp_spmm_split_f32(P(sp.hdr), P(sp.rowid), P(sp.ucol), P(sp.afr), P(sp.adr), P(sp.rinv), sp.n_tiles, P(x), feat, n * feat,
-                                        None, 0, 0, 0, P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, P(tab), 0, 0, None)
+                                        None, 0, 0, 0, P(y), feat, n * feat, sp.n_rows, sp.n_cols, batch, feat, P(tab), 0, 0, None, 0, None)
             assert isinstance(rc, int) and rc != 0
             n_plans += 1
     # reservoir layer: every dispatch branch of the launch logic (split-J, exact deal + tail, even deal, stream)
@@ -161,6 +161,7 @@ if not torch.cuda.is_available():
     assert n_plans >= 8, n_plans
 print("asan-ok", n_calls, n_plans)
 ''' % (ROOT, ASAN_LIB)
-    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1")
+    # SGP_AMD_LIB: hip.load() -- i.e. the native split planner behind op.split_plan() -- uses the ASan build as well
+    env = dict(os.environ, LD_PRELOAD=rt[-1], ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", SGP_AMD_LIB=ASAN_LIB)
     res = subprocess.run([sys.executable, "-c", child], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "asan-ok" in res.stdout, (res.stdout[-500:], res.stderr[-3000:])

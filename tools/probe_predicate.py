@@ -33,8 +33,7 @@ print("statistics + prepare         %.3f ms" % timed(lambda: hip.split_profile(x
 print("propagate (default dispatch) %.3f ms" % timed(lambda: op.propagate(x, y, x_bound=1.0)))
 mplan = op.mix_plan(D, dev)
 def skipped():
-    hip.launch_predicate(prof.flag, 0)
-    hip.spmm_mix(mplan, x, y, None, n)
+    hip.spmm_mix(mplan, x, y, None, n, pred=(prof.flag, 0))
 print("exact kernel, predicate off  %.3f ms" % timed(skipped))
 os.environ["SGP_TUNE"] = "split_guard=0"
 print("propagate, no statistics     %.3f ms" % timed(lambda: op.propagate(x, y, x_bound=1.0)))

@@ -29,7 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import sgp_amd  # noqa: E402
-from sgp_amd import hip, partition, synthetic, tune  # noqa: E402
+from sgp_amd import hip, multigpu, partition, synthetic, tune  # noqa: E402
 from sgp_amd.sgp_preprocessing import spatial_operators  # noqa: E402
 
 WORKLOADS = {
@@ -368,7 +368,8 @@ def main():
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        # explicit timeout: the first collective waits for rank 0's graph + partition (below) and RCCL's bring-up
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=multigpu.dist_timeout())
 
     w = dict(WORKLOADS[args.workload])
     if args.t_steps > 0:
@@ -376,8 +377,38 @@ def main():
         if "t_chunk" in w:
             w["t_chunk"] = min(w["t_chunk"], args.t_steps)
     N, T, F, R, L, K = w["N"], w["T"], w["F"], w["R"], w["L"], w["K"]
-    ei, ew = build_graph(w)
-    ops = spatial_operators(ei, ew, N, bidirectional=w["bidir"])
+    # graph + operators (+ the node partition of ALL ranks) are made ONCE, by rank 0; the other ranks load the
+    # operators' CSR arrays and their own blocks (round 5: every rank rebuilt the kNN graph and cut the partition --
+    # 8 x ~40 s of numpy on shared host cores in front of the first collective)
+    t_graph = time.perf_counter()
+    pplan, ei, ew = None, None, None
+    exchange = os.environ.get("SGP_BENCH_EXCHANGE", "auto")       # tests: force "packed" / "gather"
+    if rank == 0:
+        ei, ew = build_graph(w)
+        ops = spatial_operators(ei, ew, N, bidirectional=w["bidir"])
+    if world > 1 or force_dist:
+        import shutil
+        import tempfile
+        box = [None]
+        if rank == 0:
+            box[0] = tempfile.mkdtemp(prefix="sgp_bench_plan_")
+            pplan = partition.plan_partition(ops, world, exchange=exchange)
+            torch.save(dict(csr=[(o.rowptr, o.col, o.val) for o in ops], bounds=pplan.bounds, node_order=pplan.node_order,
+                            norm_inf=pplan.norm_inf), os.path.join(box[0], "meta.pt"))
+            for r in range(1, world):
+                torch.save(pplan.rank_blocks[r], os.path.join(box[0], f"blocks_r{r:02d}.pt"))
+        dist.broadcast_object_list(box, src=0)                  # (also the barrier behind rank 0's preparation)
+        if rank != 0:
+            from sgp_amd.graph import ShiftOperator
+            meta = torch.load(os.path.join(box[0], "meta.pt"), weights_only=False)
+            ops = [ShiftOperator(rp, c, v, N) for rp, c, v in meta["csr"]]
+            blocks = torch.load(os.path.join(box[0], f"blocks_r{rank:02d}.pt"), weights_only=False)
+            pplan = partition.PartitionPlan(meta["bounds"], meta["node_order"], meta["norm_inf"], N,
+                                            [blocks if r == rank else None for r in range(world)])
+        dist.barrier()
+        if rank == 0:
+            shutil.rmtree(box[0], ignore_errors=True)
+    graph_build_s = time.perf_counter() - t_graph
     nnz = ops[0].nnz()
 
     torch.manual_seed(42)                                   # same weights on every rank
@@ -387,7 +418,8 @@ def main():
                              alpha_decay=L > 1, global_attr=w["glob"])
     d_h = enc.reservoir.output_size
     if world > 1 or force_dist:
-        spatial, bounds = partition.make_partitioned_spatial(ops, K, w["glob"], force_collectives=force_dist)
+        spatial = partition.spatial_from_plan(pplan, rank, K, w["glob"], force_collectives=force_dist)
+        bounds = pplan.bounds
         lo, hi = bounds[rank], bounds[rank + 1]
         local_ops = [b.op for b in spatial.blocks]
     else:
@@ -408,13 +440,12 @@ def main():
     tc = min(T, max(1, w.get("t_chunk", T) * world))
     out = torch.empty(tc, n_own, enc.output_size, device=dev)
     state = torch.zeros(L, n_own, R, device=dev) if tc < T else None
-    for o in local_ops:                                     # plans + device CSR built once
-        if spatial is None and tune.get("hop", "split") == "split":
-            o.split_plan(dev)
-        o.tile_plan(d_h, dev)
-        if tune.get("exact", "mix") == "mix":
-            o.mix_plan(d_h, dev)
-        o.device_csr(dev)
+    # host-side plans of the hop kernels the default dispatch will run (built once per graph, or loaded from
+    # SGP_AMD_CACHE): reported as config.plan_build_s -- not part of the metric, but part of what a
+    # caller of encode_dataset waits for
+    t_plan = time.perf_counter()
+    planned = [o.prepare(d_h, dev, halo=o.num_cols > o.num_nodes) for o in local_ops]
+    plan_build_s = time.perf_counter() - t_plan
 
     hop_ms = []
     timeline = []                    # partitioned path: ("comm" | "hop", start, end) events
@@ -488,7 +519,11 @@ def main():
                        "partition": f"{world} contiguous node block(s), equal nnz"
                                     f"{', locality-reordered numbering' if order is not None else ''}",
                        "backend": backend if (world > 1 or force_dist) else "none",
-                       "gpus_visible": torch.cuda.device_count()},
+                       "gpus_visible": torch.cuda.device_count(),
+                       # fewer devices than ranks: a functional run of the partitioned path, NOT a scaling measurement
+                       "ranks_share_devices": torch.cuda.device_count() < world,
+                       "graph_build_s": round(graph_build_s, 3), "plan_build_s": round(plan_build_s, 3),
+                       "plans": planned[0]},
         }
         if hop_ms:
             all_ms = sorted(a.elapsed_ms(b) for a, b in hop_ms)

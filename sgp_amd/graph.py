@@ -60,6 +60,8 @@ class ShiftOperator:
         self.num_cols = int(num_nodes if num_cols is None else num_cols)
         self._dev = {}
         self._plans = {}
+        self._exact_seen = False        # a split-hop admission flag came back 0: the exact kernels get their plans
+        self._flag_host, self._flag_pending = None, []
 
     # ---- construction -----------------------------------------------------
     @classmethod
@@ -151,53 +153,58 @@ class ShiftOperator:
         (VALU kernel only) exists."""
         key = (feat % 64 == 0, str(device))
         if key not in self._plans:
-            plan = None
+            plan = std = None
             if feat % 64 == 0 and self.nnz() > 0:
+                from . import hip, plancache
                 if limits is None:
-                    from . import hip
                     limits = hip.tiled_limits(feat)
-                plan = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
-                                       self.num_nodes, **limits)
-                # No locality in the node numbering (e.g. a k-NN graph of stations listed in
-                # file order): tile by a locality order computed from the graph itself.
-                poor = plan is None or plan.tile_rows < 32
-                if poor and self.num_cols == self.num_nodes and self.num_nodes >= 2048 and \
-                        self.nnz() >= 8 * self.num_nodes:
-                    order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
-                    alt = build_reordered_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
-                                               self.num_nodes, order, **limits)
-                    if alt is not None and (plan is None or alt.tile_rows > plan.tile_rows):
-                        plan = alt
-                # Sparse graphs (4-row groups share few columns: the VALU kernel serves them) gain from
-                # TALL tiles: a tile stages every distinct source row of its rows once per step, so a
-                # small traffic graph as ONE tile (325 rows: the whole slab of a step, 83 KB, in LDS)
-                # stages each row once instead of once per 64-row tile (3.9x at 325 nodes).
-                if plan is not None and not plan.reordered and plan.tile_rows <= 64 and \
-                        (plan.gw is None or plan.group_fill < 0.5) and limits.get("max_tile_rows", 64) <= 64 \
-                        and plan.max_row_edges <= 32:
-                    from . import hip
-                    tl = hip.tall_tile_limits(feat)
-                    for tr in (384, 320, 256, 192, 128):
-                        if tr > tl["max_tile_rows"]:
-                            continue
-                        # LDS: staged rows (whole passes of 64) + 6 bytes per edge slot of the tile's rows
-                        rpg = 4 if tr <= 256 else 6
-                        nb = 1 if plan.max_row_edges <= 16 else 2
-                        room = 160 * 1024 - rpg * 64 * nb * 16 * 6
-                        mu = min(tl["max_union"], room // (64 * 256) * 64)
-                        tp = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
-                                             self.num_nodes, mu, tl["max_tile_rows"], 32,
-                                             candidates=(tr,)) if mu >= tr // 2 else None
-                        if tp is not None and tp.tile_rows > 128:
-                            self._plans[(key, "std")] = plan.to(device)
-                            plan = tp
-                            break
-                if plan is not None:
-                    plan = plan.to(device)
-            self._plans[key] = plan
+                tl = hip.tall_tile_limits(feat)
+                plan, std = plancache.fetch(self, "tile", (sorted(limits.items()), sorted(tl.items())),
+                                            lambda: self._build_tile_plans(limits, tl))
+            if std is not None:
+                self._plans[(key, "std")] = std.to(device)
+            self._plans[key] = None if plan is None else plan.to(device)
         if not tall and (key, "std") in self._plans:     # also on the call that built both variants
             return self._plans[(key, "std")]
         return self._plans[key]
+
+    def _build_tile_plans(self, limits, tl):
+        """Host side of ``tile_plan``: ``(plan, std)`` -- the plan the staged kernels get and, where a tall-tile plan (VALU
+        kernel only) replaced it, the <= 64-row plan as ``std``."""
+        std = None
+        plan = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, **limits)
+        # No locality in the node numbering (e.g. a k-NN graph of stations listed in
+        # file order): tile by a locality order computed from the graph itself.
+        poor = plan is None or plan.tile_rows < 32
+        if poor and self.num_cols == self.num_nodes and self.num_nodes >= 2048 and \
+                self.nnz() >= 8 * self.num_nodes:
+            order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
+            alt = build_reordered_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                       self.num_nodes, order, **limits)
+            if alt is not None and (plan is None or alt.tile_rows > plan.tile_rows):
+                plan = alt
+        # Sparse graphs (4-row groups share few columns: the VALU kernel serves them) gain from
+        # TALL tiles: a tile stages every distinct source row of its rows once per step, so a
+        # small traffic graph as ONE tile (325 rows: the whole slab of a step, 83 KB, in LDS)
+        # stages each row once instead of once per 64-row tile (3.9x at 325 nodes).
+        if plan is not None and not plan.reordered and plan.tile_rows <= 64 and \
+                (plan.gw is None or plan.group_fill < 0.5) and limits.get("max_tile_rows", 64) <= 64 \
+                and plan.max_row_edges <= 32:
+            for tr in (384, 320, 256, 192, 128):
+                if tr > tl["max_tile_rows"]:
+                    continue
+                # LDS: staged rows (whole passes of 64) + 6 bytes per edge slot of the tile's rows
+                rpg = 4 if tr <= 256 else 6
+                nb = 1 if plan.max_row_edges <= 16 else 2
+                room = 160 * 1024 - rpg * 64 * nb * 16 * 6
+                mu = min(tl["max_union"], room // (64 * 256) * 64)
+                tp = build_tile_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(),
+                                     self.num_nodes, mu, tl["max_tile_rows"], 32,
+                                     candidates=(tr,)) if mu >= tr // 2 else None
+                if tp is not None and tp.tile_rows > 128:
+                    std, plan = plan, tp
+                    break
+        return plan, std
 
     def colblock_plan(self, feat, device):
         """Column-blocked plan (``sgp_amd.colblock``, kernel ``sgp_spmm_colblock_f32``) for graphs
@@ -229,15 +236,18 @@ class ShiftOperator:
             plan = None
             base = self.tile_plan(feat, device, tall=False)
             if base is not None and base.pipe is not None and (base.group_fill >= 0.5 or not strict):
-                from . import hip, mixplan
+                from . import hip, mixplan, plancache
                 lib = hip.load()
-                order = None
-                if base.reordered:
-                    order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
-                plan = mixplan.build_mix_plan(
-                    self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, base,
-                    thr=tune.get("mix_thr", 4, int),
-                    dh=lib.sgp_spmm_mix_max_dense(int(self.num_cols > self.num_nodes)), order=order)
+                thr, dh = tune.get("mix_thr", 4, int), lib.sgp_spmm_mix_max_dense(int(self.num_cols > self.num_nodes))
+
+                def build():
+                    order = None
+                    if base.reordered:
+                        order = locality_order(self.rowptr.numpy(), self.col.numpy(), self.num_nodes)
+                    return mixplan.build_mix_plan(self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes,
+                                                  base, thr=thr, dh=dh, order=order)
+                # (the base plan is a function of the operator and the kernels' limits, which the key carries)
+                plan = plancache.fetch(self, "mix", (thr, dh, sorted(hip.tiled_limits(feat).items())), build)
                 min_share = tune.get("mix_min_share", 0.25, float) if strict else -1.0
                 if plan is not None and (plan.dense_share < min_share
                                          or plan.max_union > lib.sgp_spmm_mix_max_union()):
@@ -255,34 +265,68 @@ class ShiftOperator:
         if key not in self._plans:
             plan = None
             if self.nnz() > 0:
-                from . import hip, splitplan
+                from . import hip, plancache
                 lib = hip.load()
                 lim = dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
                            max_union=lib.sgp_spmm_split_max_union(), rows_per_wave=lib.sgp_spmm_split_rows_per_wave())
-                args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
-                plan = splitplan.build_split_plan(*args, **lim)
-                # numberings without locality (16 consecutive rows share no columns): deal the rows in a
-                # locality order of the graph itself, as the tile plans do
-                if plan is not None and plan.stats["rows_per_wave"] < 0.75 * lim["rows_per_wave"] and self.num_nodes >= 2048 and \
-                        self.num_cols == self.num_nodes:
-                    alt = splitplan.build_split_plan(*args, order=locality_order(
-                        self.rowptr.numpy(), self.col.numpy(), self.num_nodes), **lim)
-                    if alt is not None and alt.stats["staged_per_row"] < plan.stats["staged_per_row"]:
-                        plan = alt
-                # a plan that stages many rows per result row (no locality at all) loses to the other kernels
-                if plan is not None and (plan.stats["rows_per_wave"] < 0.375 * lim["rows_per_wave"] or
-                                         plan.stats["staged_per_row"] > 8):
-                    plan = None
-                if plan is None and self.max_degree() > 32 * lim["chunks"] and tune.get("split_passes", 1, int) != 0:
-                    # long rows: several passes over column segments, accumulated in place
-                    passes = splitplan.build_split_passes(*args, max_passes=12, **lim)
-                    if passes is not None and passes[0].stats["rows_per_wave"] >= 0.5 * lim["rows_per_wave"] and \
-                            passes[0].stats["staged_per_row"] <= 8:
-                        plan = SplitPasses(p.to(device) for p in passes)
+                plan = plancache.fetch(self, "split", (sorted(lim.items()), tune.get("split_passes", 1, int)),
+                                       lambda: self._build_split_plan(lim))
+                if isinstance(plan, list):
+                    plan = SplitPasses(p.to(device) for p in plan)
                 elif plan is not None:
                     plan = plan.to(device)
             self._plans[key] = plan
         return self._plans[key]
+
+    def _build_split_plan(self, lim):
+        """Host side of ``split_plan``: a SplitPlan, a list of them (long rows, one per pass) or None."""
+        from . import splitplan
+        args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
+        plan = splitplan.build_split_plan(*args, **lim)
+        # numberings without locality (16 consecutive rows share no columns): deal the rows in a
+        # locality order of the graph itself, as the tile plans do
+        if plan is not None and plan.stats["rows_per_wave"] < 0.75 * lim["rows_per_wave"] and self.num_nodes >= 2048 and \
+                self.num_cols == self.num_nodes:
+            alt = splitplan.build_split_plan(*args, order=locality_order(
+                self.rowptr.numpy(), self.col.numpy(), self.num_nodes), **lim)
+            if alt is not None and alt.stats["staged_per_row"] < plan.stats["staged_per_row"]:
+                plan = alt
+        # a plan that stages many rows per result row (no locality at all) loses to the other kernels
+        if plan is not None and (plan.stats["rows_per_wave"] < 0.375 * lim["rows_per_wave"] or
+                                 plan.stats["staged_per_row"] > 8):
+            plan = None
+        if plan is None and self.max_degree() > 32 * lim["chunks"] and tune.get("split_passes", 1, int) != 0:
+            # long rows: several passes over column segments, accumulated in place
+            passes = splitplan.build_split_passes(*args, max_passes=12, **lim)
+            if passes is not None and passes[0].stats["rows_per_wave"] >= 0.5 * lim["rows_per_wave"] and \
+                    passes[0].stats["staged_per_row"] <= 8:
+                plan = list(passes)
+        return plan
+
+    def prepare(self, feat, device, halo=False):
+        """Build (or load from the plan cache, ``sgp_amd.plancache``) the host-side plans ``propagate``'s DEFAULT dispatch
+        needs for ``feat``-wide float32 operands on ``device``, and the device CSR.  Returns the names of what was
+        prepared.  ``propagate`` does the same on first use; callers that want the one-off host work out of their
+        timed region (or want to time it: ``bench.py``'s ``plan_build_s``) call this first."""
+        from . import hip
+        self.device_csr(device)
+        if self.nnz() == 0:
+            return ["csr"]
+        made = []
+        split_ok = tune.get("hop", "split") == "split" and feat % 16 == 0 and \
+            feat <= hip.load().sgp_spmm_split_max_feat() and self.nnz() >= 8 * self.num_nodes and self.num_nodes >= 2048
+        if split_ok and self.split_plan(device) is not None:
+            made.append("split")
+            if tune.get("exact_plans", "lazy") != "eager" and not self._exact_seen:
+                return made + ["csr (behind the split hop's predicate until a flag asks for the exact kernels)"]
+        if self.tile_plan(feat, device) is not None:
+            made.append("tile")
+            if tune.get("exact", "mix") == "mix" and self.mix_plan(feat, device) is not None:
+                made.append("mix")
+        elif not made and feat % 64 == 0 and self.num_cols * feat * 4 > 3 * 2 ** 20 and self.nnz() >= 16 * self.num_nodes \
+                and tune.get("colblock", 1, int) != 0 and self.colblock_plan(feat, device) is not None:
+            made.append("colblock")
+        return made or ["csr"]
 
     def split_eligible(self, x, y, halo=None):
         """Whether ``propagate`` would pick the split-fp16 hop on its own for these operands (callers that
@@ -329,7 +373,13 @@ class ShiftOperator:
         if x.shape[0] == 0 or x.shape[2] == 0 or self.num_nodes == 0:
             self.next_bound = self.last_split_flag = None
             return y                                      # nothing to compute (an empty time chunk)
-        plan = None if force in ("csr", "colblock", "split") else \
+        self._poll_flags()
+        # (the tile plan of the exact kernels is built further down, only on the paths that use it: where the split-fp16
+        # hop is the default the exact kernels sit behind a predicate that admits them on no shipped configuration, and
+        # their plans -- 16 s of host work on the target graph -- are built the first time a flag shows they ran)
+        lazy_exact = force is None and tune.get("exact_plans", "lazy") != "eager" and not self._exact_seen and \
+            self.split_eligible(x, y, halo)
+        plan = None if force in ("csr", "colblock", "split") or lazy_exact else \
             self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,
         # far * xhrs, n_rows * yrs < 2^30); beyond that -- e.g. a [rows, T, D] halo receive buffer of a
@@ -370,6 +420,13 @@ class ShiftOperator:
                 pending = prof.flag
             elif force == "split":
                 raise NotImplementedError("no split-fp16 plan for this operator / feature width / halo / operand")
+            if lazy_exact and pending is not None:
+                # behind the predicate, until a flag says otherwise: the generic CSR kernel (exact fp32, no plan)
+                rowptr, col, val = self.device_csr(x.device)
+                hip.spmm_csr(rowptr, col, val, x, y, halo, self.num_nodes, pred=(pending, 0))
+                self._watch_flag(pending)
+                self.last_kernel, self.last_exact_kernel, self.last_split_flag = "spmm_split", "spmm_csr_rows", pending
+                return y
             plan = self.tile_plan(x.shape[2], x.device, tall=True) if fits32 else None
         name = self._propagate_exact(x, y, force, halo, plan, fits32, pending)
         if pending is not None:
@@ -388,7 +445,40 @@ class ShiftOperator:
         flag = getattr(self, "last_split_flag", None)
         if flag is None:
             return getattr(self, "last_kernel", None)
-        return "spmm_split" if int(flag.item()) == 1 else self.last_exact_kernel
+        if int(flag.item()) == 1:
+            return "spmm_split"
+        self._exact_seen = True                          # the exact path ran: its planned kernels from the next hop on
+        return self.last_exact_kernel
+
+    # ---- lazily planned exact kernels: watching the admission flags without a host sync
+    _FLAG_SLOTS = 32
+
+    def _watch_flag(self, flag):
+        """Enqueue a 4-byte copy of a split-hop admission flag into pinned host memory (+ an event): ``_poll_flags`` reads
+        it at a later ``propagate`` once the event has passed -- never a synchronisation."""
+        if self._flag_host is None:
+            self._flag_host = torch.empty(self._FLAG_SLOTS, dtype=torch.int32).pin_memory()
+            self._flag_pending = []
+        if len(self._flag_pending) >= self._FLAG_SLOTS:
+            return                                        # (every slot in flight: this hop goes unwatched)
+        used = {i for i, _ in self._flag_pending}
+        slot = next(i for i in range(self._FLAG_SLOTS) if i not in used)
+        self._flag_host[slot:slot + 1].copy_(flag, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(flag.device))
+        self._flag_pending.append((slot, ev))
+
+    def _poll_flags(self):
+        if not self._flag_pending:
+            return
+        still = []
+        for slot, ev in self._flag_pending:
+            if ev.query():
+                if int(self._flag_host[slot]) == 0:
+                    self._exact_seen = True
+            else:
+                still.append((slot, ev))
+        self._flag_pending = still
 
     def _propagate_exact(self, x, y, force, halo, plan, fits32, pending):
         """The exact-fp32 dispatch; ``pending``: device flag of a split-fp16 launch already enqueued for this hop --

@@ -21,9 +21,12 @@ environment variable ``SGP_AMD_GPUS``, else 1) that same call
 
 With ``shard_dir`` the ranks write ``.pt`` shard files instead (embeddings larger than host RAM).  When the box shows
 fewer GPUs than ranks the ranks share devices over gloo (functional check on a one-GPU box; no scaling meaning).
-/dev/shm (or ``shm_dir``) must hold input + result; no hardware scaling curve of this path exists yet (the pool's
-leases have one GPU: DESIGN.md 5).
+/dev/shm (or ``shm_dir``) must hold input + result: ``require_shm_space`` checks that BEFORE anything is mapped (a tmpfs
+over-commit surfaces as SIGBUS in the middle of a run otherwise); the result's file name is removed as soon as every rank
+has mapped it (a killed parent leaks nothing); the process group gets an explicit timeout (``SGP_AMD_DIST_TIMEOUT``
+seconds, default 1800).  No hardware scaling curve of this path exists yet (the pool's leases have one GPU: DESIGN.md 5).
 """
+import datetime
 import json
 import os
 import socket
@@ -144,6 +147,25 @@ class RankPipeline:
         main.wait_stream(self.d2h)
 
 
+def dist_timeout():
+    """Timeout of the ranks' process group: generous (the first collective waits for the slowest rank's graph plans and
+    RCCL's own bring-up over xGMI), explicit rather than the backend's default."""
+    return datetime.timedelta(seconds=int(os.environ.get("SGP_AMD_DIST_TIMEOUT", "1800")))
+
+
+def require_shm_space(shm_dir, needed_bytes, what):
+    """Fail BEFORE mapping when ``shm_dir`` cannot hold ``needed_bytes`` (tmpfs hands out pages lazily: an over-committed
+    mapping dies with SIGBUS when the ranks touch it)."""
+    st = os.statvfs(shm_dir)
+    free = st.f_bavail * st.f_frsize
+    if free < needed_bytes:
+        raise RuntimeError(
+            f"sgp_amd multi-GPU encode: {shm_dir} has {free / 2 ** 30:.1f} GiB free but {what} needs "
+            f"{needed_bytes / 2 ** 30:.1f} GiB ({needed_bytes} bytes); pass shm_dir= (a larger tmpfs / a fast disk) or "
+            f"shard_dir= (the ranks then write shard files and no host tensor is built)")
+    return free
+
+
 def _rank_main(rank, world, port, desc, x, out_file, out_shape, plan_dir, shard_dir, backend, budget):
     """One rank (spawned).  ``x``: shared-memory host tensor of the whole input; ``out_file``: the shared result's
     backing file (None with ``shard_dir``); ``plan_dir``: where the parent left this rank's partition blocks and
@@ -158,7 +180,7 @@ def _rank_main(rank, world, port, desc, x, out_file, out_shape, plan_dir, shard_
     n_dev = torch.cuda.device_count()
     torch.cuda.set_device(rank % n_dev)
     dev = torch.device("cuda", rank % n_dev)
-    dist.init_process_group(backend, rank=rank, world_size=world)
+    dist.init_process_group(backend, rank=rank, world_size=world, timeout=dist_timeout())
     try:
         enc = SGPEncoder(**desc["kwargs"])
         enc.load_state_dict(desc["state_dict"])
@@ -187,6 +209,14 @@ def _rank_main(rank, world, port, desc, x, out_file, out_shape, plan_dir, shard_
         if out_file is not None:
             numel = out_shape[0] * out_shape[1] * out_shape[2]
             out = torch.from_file(out_file, shared=True, size=max(numel, 1), dtype=torch.float32)[:numel].view(out_shape)
+            # every rank (and the parent) holds its mapping now: the NAME can go -- nothing is left behind in shm_dir
+            # if the parent is killed from here on
+            dist.barrier()
+            if rank == 0:
+                try:
+                    os.unlink(out_file)
+                except OSError:
+                    pass
         shards = []
         row_ids = rows if not isinstance(rows, slice) else torch.arange(rows.start, rows.stop)
 
@@ -218,15 +248,22 @@ def _rank_main(rank, world, port, desc, x, out_file, out_shape, plan_dir, shard_
         dist.destroy_process_group()
 
 
-def shared_result(shape, shm_dir=None):
+def default_shm_dir(shm_dir=None):
+    return shm_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
+
+
+def shared_result(shape, shm_dir=None, extra_bytes=0):
     """A float32 host tensor of ``shape`` backed by a fresh file in ``shm_dir`` (default /dev/shm) that other
-    processes can map by name: ``(tensor, path)``.  The caller unlinks the path once every process has mapped it."""
-    shm_dir = shm_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir())
-    fd, path = tempfile.mkstemp(prefix="sgp_amd_out_", suffix=".bin", dir=shm_dir)
-    os.close(fd)
+    processes can map by name: ``(tensor, path)``.  Rank 0 unlinks the path once every rank has mapped it.
+    ``extra_bytes``: what else the caller is about to put into the same filesystem (the shared input)."""
+    shm_dir = default_shm_dir(shm_dir)
     n = 1
     for d in shape:
         n *= int(d)
+    require_shm_space(shm_dir, 4 * n + extra_bytes, f"the shared result {tuple(shape)} float32"
+                      + (f" + {extra_bytes} bytes of shared input" if extra_bytes else ""))
+    fd, path = tempfile.mkstemp(prefix="sgp_amd_out_", suffix=".bin", dir=shm_dir)
+    os.close(fd)
     t = torch.from_file(path, shared=True, size=max(n, 1), dtype=torch.float32)
     return t[:n].view(*shape), path
 
@@ -259,6 +296,12 @@ def encode_multi_gpu(encoder, x, edge_index, edge_weight, gpus, out=None, shard_
     xs = x.detach()
     if xs.dtype != torch.float32 or not xs.is_contiguous():
         xs = xs.float().contiguous()
+    in_bytes = 0 if xs.is_shared() else xs.numel() * 4          # torch's shared memory lives in /dev/shm
+    out_bytes = 0 if shard_dir is not None else T * N * d_out * 4
+    if os.path.isdir("/dev/shm") and in_bytes:
+        same_fs = shard_dir is None and os.stat(default_shm_dir(shm_dir)).st_dev == os.stat("/dev/shm").st_dev
+        require_shm_space("/dev/shm", in_bytes + (out_bytes if same_fs else 0),
+                          "the shared input" + (" + result" if same_fs else ""))
     if not xs.is_shared():
         xs.share_memory_()
     if out is not None and (tuple(out.shape) != (T, N, d_out) or out.dtype != torch.float32 or not out.is_contiguous()
@@ -276,7 +319,7 @@ def encode_multi_gpu(encoder, x, edge_index, edge_weight, gpus, out=None, shard_
             torch.save(plan.rank_blocks[r], os.path.join(work, f"blocks_r{r:02d}.pt"))
         shared = None
         if shard_dir is None:
-            shared, out_path = shared_result((T, N, d_out), shm_dir)
+            shared, out_path = shared_result((T, N, d_out), shm_dir)      # (checks the free space of shm_dir again)
         else:
             os.makedirs(shard_dir, exist_ok=True)
         mp.spawn(_rank_main, args=(world, free_port(), encoder.describe(), xs, out_path, (T, N, d_out), work,

@@ -1022,7 +1022,8 @@ def _run_bench(args, env, timeout=1500):
     return json.loads(lines[0])
 
 
-def test_bench_forced_collectives_take_the_rccl_branch_on_one_rank(tmp_path):
+@pytest.mark.parametrize("exchange", ["auto", "gather"])
+def test_bench_forced_collectives_take_the_rccl_branch_on_one_rank(tmp_path, exchange):
     """SGP_BENCH_FORCE_DIST=1 with the default backend (nccl = RCCL): ONE rank runs the whole
     partitioned path -- RCCL init, the device ``all_to_all_single`` of ``HaloExchange``, the device
     ``all_reduce`` of the global block, the (hop, time chunk) pipeline on the communication stream and
@@ -1036,8 +1037,11 @@ def test_bench_forced_collectives_take_the_rccl_branch_on_one_rank(tmp_path):
     _run_bench(base, env)
     plain = torch.load(tmp_path / "out_w1_r0.pt")
     os.rename(tmp_path / "out_w1_r0.pt", tmp_path / "plain.pt")
-    rec = _run_bench(base, dict(env, SGP_BENCH_FORCE_DIST="1", MASTER_PORT=str(29900 + os.getpid() % 90)))
-    assert rec["config"]["backend"] == "nccl" and rec["n_gpus"] == 1
+    rec = _run_bench(base, dict(env, SGP_BENCH_FORCE_DIST="1", SGP_BENCH_EXCHANGE=exchange,
+                                MASTER_PORT=str(29900 + os.getpid() % 90)))
+    assert rec["config"]["backend"] == "nccl" and rec["n_gpus"] == 1 and rec["config"]["ranks_share_devices"] is False
+    assert rec["multi_gpu"]["exchange"] == ("all_gather of full shards" if exchange == "gather" else "packed all_to_all")
+    assert rec["config"]["plan_build_s"] >= 0 and rec["config"]["graph_build_s"] > 0
     assert "multi_gpu" in rec and rec["multi_gpu"]["time_chunks_per_hop"] > 1      # the pipelined branch ran
     forced = torch.load(tmp_path / "out_w1_r0.pt")
     d_h = 64

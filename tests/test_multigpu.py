@@ -36,6 +36,29 @@ def test_rank_rows_and_chunk_steps():
     assert 8 <= tc < 1000 and 4 * tc * 10000 * 384 * 4 <= 10 ** 9       # two input + two embedding slots
 
 
+def test_shm_space_is_checked_before_anything_is_mapped(tmp_path, monkeypatch):
+    """First-contact hardening (round-5 review): input + result must fit the shared filesystem BEFORE the mapping is
+    made -- tmpfs over-commit is a SIGBUS in the middle of a run otherwise; the error names the bytes."""
+    free = multigpu.require_shm_space(str(tmp_path), 1024, "a probe")
+    assert free >= 1024
+    with pytest.raises(RuntimeError, match=r"needs .* GiB \(\d+ bytes\).*shard_dir="):
+        multigpu.require_shm_space(str(tmp_path), free + (1 << 40), "the shared result")
+    # shared_result refuses a shape the directory cannot hold, and leaves no file behind
+    huge = (1 << 20, 1 << 12, 1 << 10)                                         # 16 PiB of float32
+    with pytest.raises(RuntimeError, match="shared result"):
+        multigpu.shared_result(huge, str(tmp_path))
+    assert list(tmp_path.iterdir()) == []
+    t, path = multigpu.shared_result((3, 4, 5), str(tmp_path))
+    assert tuple(t.shape) == (3, 4, 5) and os.path.exists(path)
+    os.unlink(path)
+    t.fill_(2.0)                                                               # the mapping outlives the name
+    assert float(t.sum()) == 120.0
+    monkeypatch.setenv("SGP_AMD_DIST_TIMEOUT", "77")
+    assert multigpu.dist_timeout().total_seconds() == 77
+    monkeypatch.delenv("SGP_AMD_DIST_TIMEOUT")
+    assert multigpu.dist_timeout().total_seconds() == 1800
+
+
 def test_partition_plan_cut_once_equals_every_ranks_own_cut():
     """``plan_partition`` (one process cuts all ranks' blocks: what ``encode_multi_gpu`` does in the parent) gives
     every rank exactly the blocks ``make_partitioned_spatial`` computes for itself -- also under a locality

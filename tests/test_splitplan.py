@@ -123,3 +123,35 @@ def test_native_planner_is_fast_on_a_target_shaped_graph():
     dt = time.time() - t0
     assert plan is not None and plan.stats["rows_per_wave"] > 12 and plan.stats["staged_per_row"] < 4.5
     assert dt < 2.0, f"native split planner took {dt:.2f} s for N = {n}"
+
+
+def test_plan_cache_round_trip(tmp_path, monkeypatch):
+    """SGP_AMD_CACHE: the second operator built from the same edges loads its plans instead of planning (split, tile and
+    mix plans; a changed weight is another key; a truncated file is rebuilt)."""
+    from sgp_amd import plancache
+    monkeypatch.setenv("SGP_AMD_CACHE", str(tmp_path))
+    n = 2600
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=2)
+    cpu = torch.device("cpu")
+    before = dict(plancache.stats)
+    op = ShiftOperator.from_edges(ei, ew, n)
+    a = op.split_plan(cpu)
+    ta, ma = op.tile_plan(64, cpu, tall=False), op.mix_plan(64, cpu, strict=False)
+    assert plancache.stats["stores"] - before["stores"] == 3 and plancache.stats["hits"] == before["hits"]
+    op2 = ShiftOperator.from_edges(ei, ew, n)
+    t0 = time.time()
+    b = op2.split_plan(cpu)
+    tb, mb = op2.tile_plan(64, cpu, tall=False), op2.mix_plan(64, cpu, strict=False)
+    dt = time.time() - t0
+    assert plancache.stats["hits"] - before["hits"] == 3 and dt < 1.0
+    same_plan(a, b)
+    assert torch.equal(ta.ucol, tb.ucol) and torch.equal(ta.pipe["gw"], tb.pipe["gw"]) and ta.tile_rows == tb.tile_rows
+    assert (ma is None) == (mb is None) and (ma is None or torch.equal(ma.gw, mb.gw))
+    ew2 = ew.clone()
+    ew2[0] *= 2
+    ShiftOperator.from_edges(ei, ew2, n).split_plan(cpu)
+    assert plancache.stats["hits"] - before["hits"] == 3            # another operator: a miss
+    for f in tmp_path.iterdir():
+        if f.name.startswith("split-"):
+            f.write_bytes(f.read_bytes()[:100])
+    same_plan(ShiftOperator.from_edges(ei, ew, n).split_plan(cpu), a)

@@ -453,6 +453,7 @@ def main():
     def step(timed):
         if state is not None:
             state.zero_()
+            hip.mark_unit_bounded(state)              # (zero lies inside [-1, 1]; an in-place edit drops the mark)
         for t0 in range(0, T, tc):
             xs, oc = x[t0:t0 + tc], out[:min(tc, T - t0)]
             if spatial is None:

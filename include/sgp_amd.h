@@ -249,6 +249,13 @@ int sgp_split_prepare_f32(const float* stats, double n_samples, double s_eff, in
  * chunks = sgp_spmm_split_chunks(), max_union = sgp_spmm_split_max_union().  feat % 16 == 0, feat <=
  * sgp_spmm_split_max_feat().  X / X_halo / n_own as in sgp_spmm_tiled_f32 (columns >= n_own address the halo rows
  * a node partition received).  x_tab: device [2][feat], scale then inverse, |x[:, c]| * x_tab[c] < 65504.
+ * NON-FINITE OPERANDS.  The kernel multiplies dense 16 x 32 blocks: padded and zero entries form 0 * x, so a NaN /
+ * inf in a source row (or a value that overflows fp16 after scaling: |x| above its column's bound by 4x) reaches EVERY
+ * result row of every wave that stages that row, not only the row's graph neighbours as in a sparse fp32 product.
+ * sgp_split_prepare_f32's admission test sees non-finite values only in the rows and steps its statistics read: all of
+ * them when the bound is measured (full = 1), a sample (~8 steps, every r-th row) when the caller supplies an a-priori
+ * bound.  A caller that passes a bound therefore vouches for finiteness and for the bound on the unsampled part
+ * (sgp_amd's encoders pass one only for states their own bounded-activation reservoir kernels wrote).
  * accumulate != 0: Y += A X (the later passes of an operator whose rows were cut into column segments).
  * t_chunk = time steps per workgroup (0 = chosen here). */
 int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,

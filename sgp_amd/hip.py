@@ -370,6 +370,19 @@ def abs_max(x):
     return float(out.item())
 
 
+def mark_unit_bounded(state):
+    """Record that every entry of ``state`` lies in [-1, 1] NOW (a zeroed state, or one a bounded-activation reservoir of
+    this package left): the a-priori bound 1 of the split-fp16 hop may be used for what the recurrence produces from it.
+    The mark is tied to the tensor's version counter: any in-place edit by the caller (``state.mul_(5)``) invalidates it
+    (the kernels write through raw pointers and leave the counter alone)."""
+    state._sgp_unit_bounded = state._version
+    return state
+
+
+def is_unit_bounded(state):
+    return state is not None and getattr(state, "_sgp_unit_bounded", None) == state._version
+
+
 class ColumnBound:
     """Per-column upper bounds of |x| as a DEVICE tensor ``[feat]`` (what ``split_profile`` leaves for the next hop:
     ``bound * ||A||_inf``); a column whose bound is 0 is identically zero."""

@@ -204,7 +204,7 @@ def _rank_main(rank, world, port, desc, x, out_file, out_shape, plan_dir, shard_
         tc = int(tcs.item())
         L, R = len(enc.reservoir.reservoir_layers), enc.reservoir.hidden_size
         state = torch.zeros(L, n_own, R, dtype=torch.float32, device=dev)
-        state._sgp_unit_bounded = True                          # starts at zero (SGPEncoder._state_bound)
+        hip.mark_unit_bounded(state)                          # starts at zero (SGPEncoder._state_bound)
         out = None
         if out_file is not None:
             numel = out_shape[0] * out_shape[1] * out_shape[2]

@@ -149,7 +149,9 @@ class SGPEncoder(nn.Module):
         # 14.2 ms against 14.8 in one piece, 14.5 in 8 and 15.0 in 16 -- every piece costs a launch gap of the chain
         pieces = self.overlap_chunks if share >= 0.5 else 8 if share >= 0.25 else 4 if share >= 0.1 else 1
         pieces = tune.get("overlap_chunks", pieces, int)
-        return pieces if T >= 64 * pieces else 1
+        while pieces > 1 and T < 64 * pieces:                  # a sequence too short for the count takes the next smaller one
+            pieces //= 2
+        return max(1, pieces)
 
     def _state_bound(self, state=None):
         """Upper bound of |reservoir state| where one holds: a leaky average ``(1 - a) h + a act(.)`` of values in
@@ -162,7 +164,7 @@ class SGPEncoder(nn.Module):
             return None
         if not all(0.0 <= float(l.alpha) <= 1.0 for l in self.reservoir.reservoir_layers):
             return None
-        if state is not None and not getattr(state, "_sgp_unit_bounded", False):
+        if state is not None and not hip.is_unit_bounded(state):
             return None
         return 1.0
 
@@ -184,12 +186,12 @@ class SGPEncoder(nn.Module):
             self.reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
             self.sgp_encoder.encode_into(out, d_h, ops, timeline, col_sums=sums, x_bound=x_bound)
             if state is not None and x_bound is not None:
-                state._sgp_unit_bounded = True                  # (carried on: encode_streamed, the time pieces below)
+                hip.mark_unit_bounded(state)                  # (carried on: encode_streamed, the time pieces below)
             return out
         if state is None:
             state = torch.zeros(len(self.reservoir.reservoir_layers), N, self.reservoir.hidden_size,
                                 dtype=torch.float32, device=x.device)
-            state._sgp_unit_bounded = True
+            hip.mark_unit_bounded(state)
         main = torch.cuda.current_stream(x.device)
         key = str(x.device)
         if key not in self._side_streams:
@@ -274,7 +276,7 @@ class SGPEncoder(nn.Module):
             return out
         out_pinned = out.is_pinned()
         state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
-        state._sgp_unit_bounded = True                          # starts at zero (see _state_bound)
+        hip.mark_unit_bounded(state)                          # starts at zero (see _state_bound)
         nbuf = 2 if len(starts) > 1 else 1
         xin = [torch.empty(tc, N, F, dtype=torch.float32, device=dev) for _ in range(nbuf)]
         buf = [torch.empty(tc, N, D, dtype=torch.float32, device=dev) for _ in range(nbuf)]
@@ -383,7 +385,7 @@ class SGPEncoder(nn.Module):
         per_step = N * (F + D) * 4
         ts = max(1, min(int(shard_steps), T, self._budget() // max(1, 2 * per_step)))
         state = torch.zeros(L, N, R, dtype=torch.float32, device=dev)
-        state._sgp_unit_bounded = True                          # starts at zero (see _state_bound)
+        hip.mark_unit_bounded(state)                          # starts at zero (see _state_bound)
         buf = torch.empty(ts, N, D, dtype=torch.float32, device=dev)
         pin = torch.empty(ts, N, D, dtype=torch.float32, pin_memory=True)
         paths = []

@@ -66,6 +66,7 @@ class ReservoirLayer(nn.Module):
         self.w_hh.data.copy_(w_rec)
         if bias is not None:
             self.b_ih.data.copy_(bias)
+        self._act_key = None
 
     def _device_weights(self, device):
         b = self.b_ih if self.b_ih is not None else torch.zeros(self.hidden_size)
@@ -79,8 +80,22 @@ class ReservoirLayer(nn.Module):
         resolves to fp32's RELATIVE accuracy: such layers run with ``tanh_rel`` (odd polynomial below 0.25, +4-15 % time)."""
         if self.activation_name != "tanh":
             return self.activation_name
-        b = self.b_ih                   # (looked at on every call: `.data` edits do not bump a version counter)
-        return "tanh_rel" if b is None or float(b.detach().abs().max()) < 0.25 else "tanh"
+        b = self.b_ih
+        if b is None:
+            return "tanh_rel"
+        if not b.is_cuda:
+            # host weights (the default: the reference's modules live on the CPU): looked at on every call -- a few
+            # hundred floats, and `.data` edits do not bump a version counter
+            return "tanh_rel" if float(b.detach().abs().max()) < 0.25 else "tanh"
+        # a module moved to the GPU: the read is a device-to-host sync on the current stream -- once per layer and time
+        # piece in front of the chain's launches, where the host then waits for the previous piece and enqueues the
+        # hops late.  Decided once per (storage, version) of the bias instead; weights set through copy_ / load_state_dict
+        # / reset_parameters / .to() change that key, an edit through ``.data`` of a GPU-resident bias needs
+        # ``layer._act_key = None``.
+        key = (b.data_ptr(), b._version)
+        if getattr(self, "_act_key", None) != key:
+            self._act_key, self._act_name = key, ("tanh_rel" if float(b.detach().abs().max()) < 0.25 else "tanh")
+        return self._act_name
 
     def run_sequence(self, x, out, h_state=None):
         """x[T, M, F] -> out[T, M, R] on the device (strided views allowed)."""

@@ -380,7 +380,7 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     bound = None
     if x.is_cuda and getattr(reservoir, "mode", None) in ("tanh", "self_norm") and \
             all(0.0 <= float(l.alpha) <= 1.0 for l in reservoir.reservoir_layers) and \
-            (state is None or getattr(state, "_sgp_unit_bounded", False)):
+            (state is None or hip.is_unit_bounded(state)):
         bound = 1.0
     pieces = spatial.n_chunks if pieces is None else pieces
     pieces = max(1, min(int(pieces), T // 8)) if x.is_cuda else 1
@@ -393,7 +393,7 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
         state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
                             dtype=torch.float32, device=x.device)
     if bound is not None:
-        state._sgp_unit_bounded = True
+        hip.mark_unit_bounded(state)
     main = torch.cuda.current_stream(x.device)
     if spatial._res_stream is None:
         spatial._res_stream = torch.cuda.Stream(device=x.device)

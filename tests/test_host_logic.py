@@ -477,7 +477,33 @@ def test_small_graph_pipeline_pieces_follow_the_hops_share_of_the_chain(monkeypa
                             density=.7, input_scaling=1., receptive_field=2, bidirectional=False, alpha_decay=False,
                             global_attr=False)
     assert bay._overlap_pieces(52116, 325) == 16 and la._overlap_pieces(34272, 207) == 4
-    assert bay._overlap_pieces(1000, 325) == 1                # fewer than 64 steps per piece
+    assert bay._overlap_pieces(1000, 325) == 8 and bay._overlap_pieces(100, 325) == 1   # >= 64 steps per piece: the next smaller count
     assert bay._overlap_pieces(52116, 16 * bay.overlap_tiles + 1) == 1
     monkeypatch.setenv("SGP_TUNE", "overlap_chunks=2")
     assert bay._overlap_pieces(52116, 325) == 2 and la._overlap_pieces(34272, 207) == 2
+
+
+def test_unit_bound_mark_follows_the_tensor_version():
+    """The a-priori bound 1 of the split-fp16 hop may be used for a carried state only while nobody edited it: the
+    mark is tied to the tensor's version counter (round-5 advice: a Python attribute survived ``state.mul_(5)``)."""
+    from sgp_amd import hip
+    state = torch.zeros(2, 5, 4)
+    assert not hip.is_unit_bounded(state) and not hip.is_unit_bounded(None)
+    hip.mark_unit_bounded(state)
+    assert hip.is_unit_bounded(state)
+    state.mul_(5)
+    assert not hip.is_unit_bounded(state)
+    hip.mark_unit_bounded(state.zero_())
+    assert hip.is_unit_bounded(state)
+
+
+def test_overlap_pieces_walk_down_for_short_sequences():
+    """A sequence too short for the chosen piece count takes the next smaller count, not one piece (round-5 advice)."""
+    import sgp_amd
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=128, reservoir_layers=1, leaking_rate=0.8, spectral_radius=0.9,
+                             density=0.7, input_scaling=1., receptive_field=4, bidirectional=True, alpha_decay=False,
+                             global_attr=True)
+    full = enc._overlap_pieces(52116, 325)
+    assert full == 16
+    assert enc._overlap_pieces(800, 325) == 8 and enc._overlap_pieces(300, 325) == 4 and enc._overlap_pieces(100, 325) == 1
+    assert enc._overlap_pieces(52116, 100000) == 1                      # large graphs: no pieces

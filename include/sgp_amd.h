@@ -43,7 +43,8 @@ extern "C" {
 #endif
 
 /* 3 (round 6): the launch predicate became the explicit trailing (pred, run_if) pair of every sgp_spmm_*_f32 entry
- * (sgp_launch_predicate removed); host-side planner sgp_split_plan_deal / sgp_split_plan_fill added.
+ * (sgp_launch_predicate removed); host-side planner sgp_split_plan_deal / sgp_split_plan_fill and the time-piece
+ * reservoir entry sgp_reservoir_pieces_f32 added.
  * 2 (round 5): sgp_spmm_split_f32 takes per-column scale tables and a per-row plan array; sgp_col_stats_f32,
  * sgp_split_prepare_f32, sgp_launch_predicate added; round 4 had already removed sgp_spmm_mfma / pipe / blk_*, widened
  * sgp_spmm_colblock_f32 by the halo arguments and grown sgp_reservoir_workspace_bytes (bf16-piece fragments). */
@@ -365,6 +366,27 @@ int sgp_reservoir_f32(const float* x, int64_t x_row_stride, int64_t x_step_strid
                       float* h_state, void* workspace,
                       int32_t T, int32_t N, int32_t F, int32_t R,
                       sgp_stream_t stream);
+
+/* The same layer over n_pieces TIME PIECES side by side (small graphs: the sequential chain of
+ * lib/nn/reservoir/reservoir.py:170-183 runs on ceil(N / 16) workgroups -- 21 of 256 CUs at N = 325 -- so the time axis
+ * is the only parallelism left).  Workgroup (node tile, p) runs t_piece steps (the last piece: t_last <= t_piece) of
+ *     x + p * x_piece_stride, out + p * out_piece_stride, h_state + p * N * R        (strides in floats)
+ * from the state h_state[p] and leaves its final state there; no_store != 0 writes no output rows (a piece's WARM-UP:
+ * started from zero some hundred steps early, a contractive recurrence arrives at the true state).  The recurrence
+ * itself is not changed: what makes the pieces a valid evaluation of the sequence is the caller's comparison of every
+ * piece's end state with its successor's warmed-up start (sgp_amd/nn/reservoir/reservoir.py::run_time_parallel, on the
+ * device) and the sequential launch -- this entry with n_pieces = 1 under `pred` -- that repairs a rejected splice.
+ * pred / run_if: launch predicate as on the hop entries.  Served by the split-J bf16-piece kernel only
+ * (csrc/reservoir_splitj_bf3.h: 32 < R <= 128, F <= 64, <= 512 node tiles); anything else returns SGP_EUNSUP. */
+int sgp_reservoir_pieces_f32(const float* x, int64_t x_row_stride, int64_t x_step_stride,
+                             const float* w_ih, const float* w_hh, const float* b,
+                             double alpha, int32_t act,
+                             float* out, int64_t out_row_stride, int64_t out_step_stride,
+                             float* h_state, void* workspace,
+                             int32_t t_piece, int32_t t_last, int32_t n_pieces,
+                             int64_t x_piece_stride, int64_t out_piece_stride, int32_t no_store,
+                             int32_t N, int32_t F, int32_t R,
+                             const int32_t* pred, int32_t run_if, sgp_stream_t stream);
 
 /* All L layers of a narrow stacked reservoir in ONE launch (lib/nn/reservoir/reservoir.py:170-180:
  * the reference steps every layer inside one time step, layer l consuming layer l-1's new state).

@@ -291,6 +291,16 @@ int64_t sgp_reservoir_workspace_bytes(int32_t F, int32_t R) {
     return (body + 255) / 256 * 256 + 1024;                                        // + the split-J form's dump area (last KB)
 }
 
+struct Pieces { int n, t_last, no_store; long long px, po, ps; const int* pred; int run_if; };
+
+static int reservoir_run(const float* x, int64_t xrs, int64_t xss,
+                         const float* w_ih, const float* w_hh, const float* b,
+                         double alpha, int32_t act,
+                         float* out, int64_t ors, int64_t oss,
+                         float* h_state, void* workspace,
+                         int32_t T, int32_t N, int32_t F, int32_t R, const Pieces& pc,
+                         sgp_stream_t stream);
+
 int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
                       const float* w_ih, const float* w_hh, const float* b,
                       double alpha, int32_t act,
@@ -298,6 +308,36 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
                       float* h_state, void* workspace,
                       int32_t T, int32_t N, int32_t F, int32_t R,
                       sgp_stream_t stream) {
+    return reservoir_run(x, xrs, xss, w_ih, w_hh, b, alpha, act, out, ors, oss, h_state, workspace, T, N, F, R,
+                         Pieces{1, T, 0, 0, 0, 0, nullptr, 0}, stream);
+}
+
+int sgp_reservoir_pieces_f32(const float* x, int64_t xrs, int64_t xss,
+                             const float* w_ih, const float* w_hh, const float* b,
+                             double alpha, int32_t act,
+                             float* out, int64_t ors, int64_t oss,
+                             float* h_state, void* workspace,
+                             int32_t t_piece, int32_t t_last, int32_t n_pieces,
+                             int64_t x_piece_stride, int64_t out_piece_stride, int32_t no_store,
+                             int32_t N, int32_t F, int32_t R,
+                             const int32_t* pred, int32_t run_if, sgp_stream_t stream) {
+    SGP_REQUIRE(n_pieces >= 1 && t_piece >= 0 && t_last >= 0 && t_last <= t_piece, "sgp_reservoir_pieces_f32: bad piece sizes");
+    SGP_REQUIRE(n_pieces == 1 || h_state, "sgp_reservoir_pieces_f32: several pieces need their states [n_pieces][N][R]");
+    SGP_REQUIRE(n_pieces <= 65535, "sgp_reservoir_pieces_f32: at most 65535 pieces");
+    return reservoir_run(x, xrs, xss, w_ih, w_hh, b, alpha, act, out, ors, oss, h_state, workspace, t_piece, N, F, R,
+                         Pieces{n_pieces, n_pieces > 1 ? t_last : t_piece, no_store != 0, x_piece_stride, out_piece_stride,
+                                (long long)N * R, pred, run_if}, stream);
+}
+
+}  // extern "C"
+
+static int reservoir_run(const float* x, int64_t xrs, int64_t xss,
+                         const float* w_ih, const float* w_hh, const float* b,
+                         double alpha, int32_t act,
+                         float* out, int64_t ors, int64_t oss,
+                         float* h_state, void* workspace,
+                         int32_t T, int32_t N, int32_t F, int32_t R, const Pieces& pc,
+                         sgp_stream_t stream) {
     SGP_REQUIRE(x && w_ih && w_hh && b && out && workspace, "sgp_reservoir_f32: null pointer");
     SGP_REQUIRE(T >= 0 && N >= 0 && F > 0 && R > 0, "sgp_reservoir_f32: bad size");
     SGP_REQUIRE(act >= SGP_ACT_TANH && act <= SGP_ACT_TANH_REL, "sgp_reservoir_f32: unknown activation %d", act);
@@ -332,7 +372,8 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     a.wp_h16 = nullptr;
     a.wp_h16l = nullptr; a.wp_h16s = nullptr;
     a.dump = reinterpret_cast<float*>((char*)workspace + sgp_reservoir_workspace_bytes(F, R) - 1024);
-    a.bad_state = nullptr; a.pred = nullptr; a.pred_want = 0;
+    a.bad_state = nullptr; a.pred = pc.pred; a.pred_want = pc.run_if;
+    a.n_pieces = pc.n; a.t_last = pc.t_last; a.no_store = pc.no_store; a.px = pc.px; a.po = pc.po; a.ps = pc.ps;
     // res_bf3 = 0 (SGP_TUNE) keeps the exact-fp32 products for narrow reservoirs too
     static const bool use_bf3 = sgp::tune("res_bf3", 1) != 0;
     // (the split-J form for small N -- R = 64 / 128, up to 32 input features -- takes any R <= 16 jt, F <= 4 nkx: padded
@@ -404,5 +445,3 @@ int sgp_reservoir_f32(const float* x, int64_t xrs, int64_t xss,
     }
     return sgp::fail(SGP_EUNSUP, "sgp_reservoir_f32: unreachable");
 }
-
-}  // extern "C"

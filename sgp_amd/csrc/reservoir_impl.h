@@ -86,7 +86,13 @@ struct ResArgs {
     float alpha, one_minus_alpha;
     int act, T, N, F, R;
     int tiles_per_wave, n_tiles;
+    // time pieces side by side (sgp_reservoir_pieces_f32; split-J bf16-piece kernel only): workgroup (tile, p) runs piece p
+    // -- x + p * px, out + p * po, h_state + p * ps, T steps (the last piece: t_last) -- and with no_store leaves only its
+    // final state behind (the warm-up of a piece that starts from zero)
+    int n_pieces, t_last, no_store;
+    long long px, po, ps;
 };
+inline bool wants_pieces(const ResArgs& a) { return a.n_pieces > 1 || a.no_store || a.pred != nullptr; }
 
 // waves per SIMD the register budget is sized for (more co-resident waves = the MFMA pipe
 // stays busy while another wave runs its activation / loads / stores)
@@ -1375,10 +1381,11 @@ int launch_splitj(const ResArgs& a, int n_tiles, hipStream_t s) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
             if (e != hipSuccess) return sgp::fail((int)e, "reservoir: LDS opt-in: %s", hipGetErrorString(e));
-            hipLaunchKernelGGL(kern, dim3(n_tiles), dim3(256), (size_t)bytes, s, b);
+            hipLaunchKernelGGL(kern, dim3(n_tiles, a.n_pieces > 1 ? a.n_pieces : 1), dim3(256), (size_t)bytes, s, b);
             return sgp::check_launch("reservoir_layer_splitj_bf3");
         }
     }
+    if (wants_pieces(a)) return sgp::fail(SGP_EUNSUP, "reservoir: time pieces / predicate need the split-J bf16-piece kernel");
     auto kern = ov ? reservoir_layer_splitj<JT, NKX, true> : reservoir_layer_splitj<JT, NKX, false>;
     const int bytes = (int)splitj_lds_bytes<JT, NKX>();
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -1400,6 +1407,7 @@ int launch_nt(const ResArgs& a, hipStream_t s) {
         if (n_tiles <= splitj_max)
             return launch_splitj<JT, NKX>(a, n_tiles, s);
     }
+    if (wants_pieces(a)) return sgp::fail(SGP_EUNSUP, "reservoir: time pieces / predicate serve graphs of <= 512 node tiles");
     if constexpr (JT <= 4 && kSplitj) {
         // Large N: 1024 SIMDs x `per` tiles exactly (reservoir_layer's exact deal), and the L < 1024
         // tiles that are left as a split-J tail: 4 SIMDs share a tile there, a workgroup steps through

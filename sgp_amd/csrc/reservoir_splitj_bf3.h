@@ -148,7 +148,7 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
     };
     bool st_ok[JW];
 #pragma unroll
-    for (int w = 0; w < JW; ++w) st_ok[w] = ok && 16 * (wave * JW + w) + 4 * q < a.R;
+    for (int w = 0; w < JW; ++w) st_ok[w] = !a.no_store && ok && 16 * (wave * JW + w) + 4 * q < a.R;
     float* orow = a.out + (long long)node * a.ors + 16 * (wave * JW) + 4 * q;       // this lane's piece of step 0's row
     // OVEC: every lane stores 16 bytes per tile and step, unconditionally -- lanes without a row (or a padded unit) into a
     // dump area behind the packed weights -- through a running pointer: no exec-masked branch, no 64-bit product per step
@@ -392,6 +392,16 @@ __device__ __forceinline__ void splitj_bf3_body(const ResArgs& a) {
 
 template <int JT, int NKX, bool OVEC, int ACT>
 __global__ __launch_bounds__(256) void reservoir_layer_splitj_bf3(ResArgs a) {
+    if (a.pred != nullptr && a.pred[0] != a.pred_want) return;
+    if (a.n_pieces > 1) {
+        // time piece blockIdx.y of this node tile (sgp_reservoir_pieces_f32): its own rows of x / out, its own state
+        const int p = blockIdx.y;
+        a.x += p * a.px;
+        a.out += p * a.po;
+        if (a.h_state) a.h_state += p * a.ps;
+        if (p == a.n_pieces - 1) a.T = a.t_last;
+        if (a.T <= 0) return;
+    }
     if constexpr (ACT == SGP_ACT_TANH) {
         if (a.wp_h16) {
             // the two-piece fp16 loop needs the state inside [-1, 1] at every step: true from step 1 on, checked here for

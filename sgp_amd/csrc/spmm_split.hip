@@ -112,6 +112,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 struct SplitArgs {
     const int* hdr; const int* rowid; const int* ucol; const h8* afr; const int* adr; const float* rinv;
     int n_tiles, tiles_per_xcd;
+    int time_major;                          // 1: an XCD walks ITS time chunks (chunk % 8 == xcd) over ALL tiles -- a step's whole slab stays in its L2
     const float* X; long long xrs, xbs;
     const float* XH; long long xhrs, xhbs;   // halo source (columns >= n_own): local block of a node partition
     int n_own;
@@ -220,8 +221,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
     // XCD x (= blockIdx % 8) walks its own contiguous range of tiles, time chunk by time chunk, so the 32
     // workgroups an XCD runs side by side are neighbouring tiles of the same steps (their staged rows overlap)
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int tile = xcd * a.tiles_per_xcd + j % a.tiles_per_xcd;
-    const int tchunk = j / a.tiles_per_xcd;
+    // small operators (the source rows of one step fit an L2): time-major -- every tile of a time chunk runs on the SAME
+    // XCD side by side, so a staged row is fetched from the fabric once per step instead of once per XCD that holds a
+    // tile referencing it
+    const int tile = a.time_major ? j % a.n_tiles : xcd * a.tiles_per_xcd + j % a.tiles_per_xcd;
+    const int tchunk = a.time_major ? (j / a.n_tiles) * 8 + xcd : j / a.tiles_per_xcd;
     if (tile >= a.n_tiles) return;
     const int t_begin = tchunk * a.t_chunk;
     const int t_end = min(a.batch, t_begin + a.t_chunk);
@@ -511,6 +515,12 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
         }
         if (t_chunk <= 0) t_chunk = 8;
     }
+    // time-major mapping where one step's source rows (n_cols x feat floats) fit an XCD's L2 beside the result rows
+    // streaming out (SGP_TUNE=split_time_major=0|1 overrides; split_tc = time steps per workgroup there)
+    static const long tm_tune = sgp::tune("split_time_major", -1);
+    static const long tm_tc = sgp::tune("split_tc", 0);
+    a.time_major = tm_tune >= 0 ? (int)(tm_tune != 0) : 0;
+    if (a.time_major && tm_tc > 0) t_chunk = (int)tm_tc;
     a.t_chunk = t_chunk;
 #ifdef SGP_ABLATION
     static const int abl = (int)sgp::tune("split_abl", 0);
@@ -526,7 +536,8 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     const int lds_bytes = NBUF * BUF + 2 * feat * 4;
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, NBUF * BUF + 2 * MAXFEAT * 4);
     if (e != hipSuccess) return sgp::fail((int)e, "spmm_split: LDS attribute: %s", hipGetErrorString(e));
-    const unsigned grid = 8u * (unsigned)a.tiles_per_xcd * (unsigned)n_tchunks;
+    const unsigned grid = a.time_major ? 8u * (unsigned)n_tiles * (unsigned)((n_tchunks + 7) / 8)
+                                       : 8u * (unsigned)a.tiles_per_xcd * (unsigned)n_tchunks;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), lds_bytes, (hipStream_t)stream, a);
     if (abl & 256) {
         unsigned long long h[8 * NW * 8];

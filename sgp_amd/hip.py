@@ -65,6 +65,13 @@ SIGNATURES = {
                                          c_p, c_i64, c_i64,
                                          c_p, c_p,
                                          c_i32, c_i32, c_i32, c_i32, c_p]),
+    "sgp_reservoir_pieces_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
+                                                c_p, c_p, c_p,
+                                                c_f64, c_i32,
+                                                c_p, c_i64, c_i64,
+                                                c_p, c_p,
+                                                c_i32, c_i32, c_i32, c_i64, c_i64, c_i32,
+                                                c_i32, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_reservoir_fused_workspace_bytes": (c_i64, [c_i32, c_i32, c_i32]),
     "sgp_reservoir_fused_supported": (c_i32, [c_i32, c_i32, c_i32]),
     "sgp_reservoir_fused_f32": (ctypes.c_int, [c_p, c_i64, c_i64,
@@ -622,6 +629,35 @@ def reservoir_layer(x, w_ih, w_hh, b, alpha, activation, out, h_state=None):
         float(alpha), ACT_CODES[activation], op, ors, oss,
         h_state.data_ptr() if h_state is not None else None, ws.data_ptr(),
         T, N, F, R, _stream(x)), "sgp_reservoir_f32")
+    return out
+
+
+@_on_device
+def reservoir_pieces(x, w_ih, w_hh, b, alpha, activation, out, states, t_piece, t_last, x_piece_stride, out_piece_stride,
+                     no_store=False, pred=None):
+    """``sgp_reservoir_pieces_f32``: ``states[P, N, R]`` (contiguous) holds every piece's initial state and receives its
+    final one; piece p reads ``x`` / writes ``out`` at p times the piece strides (in floats) from the given views'
+    first element.  ``states[N, R]`` or None with one piece: the sequential layer, optionally under ``pred``."""
+    lib = require_gpu()
+    xp, xrs, xss = _view3(x, "x")
+    op, ors, oss = _view3(out, "out")
+    N, F = x.shape[1], x.shape[2]
+    R = w_hh.shape[0]
+    for name, w, shape in (("w_ih", w_ih, (R, F)), ("w_hh", w_hh, (R, R)), ("b", b, (R,))):
+        if tuple(w.shape) != shape or w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+            raise ValueError(f"{name}: expected contiguous float32 CUDA {shape}")
+    P = 1 if states is None or states.dim() == 2 else states.shape[0]
+    if states is not None and (not states.is_contiguous() or tuple(states.shape[-2:]) != (N, R)):
+        raise ValueError("states: expected contiguous [P, N, R] (or [N, R])")
+    wsb = lib.sgp_reservoir_workspace_bytes(F, R)
+    if wsb < 0:
+        raise NotImplementedError(f"reservoir kernel supports input/hidden sizes <= 256 (got F={F}, R={R})")
+    ws = _workspace(x.device, wsb)
+    _check(lib.sgp_reservoir_pieces_f32(
+        xp, xrs, xss, w_ih.data_ptr(), w_hh.data_ptr(), b.data_ptr(), float(alpha), ACT_CODES[activation],
+        op, ors, oss, states.data_ptr() if states is not None else None, ws.data_ptr(),
+        int(t_piece), int(t_last), P, int(x_piece_stride), int(out_piece_stride), int(bool(no_store)),
+        N, F, R, *_pred(pred), _stream(x)), "sgp_reservoir_pieces_f32")
     return out
 
 

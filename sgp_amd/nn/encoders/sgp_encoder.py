@@ -177,6 +177,8 @@ class SGPEncoder(nn.Module):
         if out is None:
             out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
         chunks = self._overlap_pieces(T, N)
+        if chunks > 1 and self.reservoir.time_parallel(T, N, x.device):
+            chunks = 1                                        # the reservoir runs as time pieces on the whole chip, then the hops
         x_bound = self._state_bound(state)
         # global_attr: the column sums of the states come from the reservoir kernel where it has them
         # in registers (fused stacked kernel); the other kernels keep the fused mean + broadcast pass

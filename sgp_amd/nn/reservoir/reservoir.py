@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import hip
+from ... import hip, tune
 from .init import draw_reservoir_weights
 
 _ACTIVATIONS = ['tanh', 'relu', 'self_norm', 'identity']
@@ -100,8 +100,84 @@ class ReservoirLayer(nn.Module):
     def run_sequence(self, x, out, h_state=None):
         """x[T, M, F] -> out[T, M, R] on the device (strided views allowed)."""
         w_ih, w_hh, b = self._device_weights(x.device)
-        return hip.reservoir_layer(x, w_ih, w_hh, b, self.alpha, self.kernel_activation(),
-                                   out, h_state)
+        act = self.kernel_activation()
+        self.last_time_parallel = None
+        plan = self.time_parallel_plan(x.shape[0], x.shape[1], x.shape[2], x.device, act) if x.is_cuda else None
+        if plan is not None:
+            try:
+                return self._run_time_parallel(x, out, h_state, plan, (w_ih, w_hh, b), act)
+            except NotImplementedError:
+                pass                                      # (a shape the piece kernel does not serve: one chain)
+        return hip.reservoir_layer(x, w_ih, w_hh, b, self.alpha, act, out, h_state)
+
+    # ---- small graphs: time pieces side by side (reservoir.py:170-183 is a serial chain of T steps; at N = 207 / 325 it
+    # occupies 13 / 21 of the chip's 256 compute units)
+    # Steps a piece is started early, from zero (None: from the leaky recurrence's nominal contraction rate (1 - a) + a rho,
+    # enough for 1e-7 -- 192 steps at rho = a = 0.9; measured there: the gap is at its floor after 64).
+    time_parallel_warm = None
+    # A splice is accepted when the warmed-up state is this close (max-abs) to the true one.  Two fp32 evaluations of the
+    # same contractive recurrence from different starts do not meet exactly: their gap settles at the rounding floor,
+    # measured 3.0e-7 .. 4.4e-7 on the C1 / C2 shapes for every warm-up from 64 to 512 steps (profiles/r6/
+    # time_parallel_probe.log) -- the distance of either from the fp64 trajectory is 5e-7.  1e-6 = 2.5x that floor,
+    # a tenth of the encoder's 1e-5.
+    time_parallel_tol = 1e-6
+
+    def time_parallel_plan(self, T, N, F, device, act=None):
+        """``(pieces, steps per piece, warm-up steps)`` when this layer's sequence may be cut into time pieces that run
+        side by side, else None.  Premises: a CONTRACTIVE recurrence -- tanh with a leaking rate in [0, 1]: a piece
+        started ``warm`` steps early from zero then arrives at the true state (the echo-state property the reference's
+        spectral-radius rescaling is there to give, reservoir.py:74-75) -- and a shape the piece kernel serves.  Whether a
+        given reservoir really forgets fast enough is NOT assumed: every splice is checked on the device and a miss reruns
+        the sequential chain (``_run_time_parallel``).  relu / identity / self_norm, leaking rates outside [0, 1] and
+        layers with tiny biases (``tanh_rel``: states far below the absolute tolerance) never take this path."""
+        act = act or self.kernel_activation()
+        if act != "tanh" or not (0.0 <= float(self.alpha) <= 1.0) or tune.get("time_parallel", 1, int) == 0:
+            return None
+        R = self.hidden_size
+        tiles = (N + 15) // 16
+        if not (32 < R <= 128 and F <= 64) or tiles < 1:
+            return None
+        warm = tune.get("time_parallel_warm", self.time_parallel_warm or 0, int)
+        if warm <= 0:
+            rate = (1.0 - float(self.alpha)) + float(self.alpha) * float(self.spectral_radius)
+            if not (0.0 < rate < 0.999):
+                return None                               # nominally not contractive (or so slowly that no warm-up pays)
+            warm = min(4096, -(-int(np.ceil(np.log(1e-7) / np.log(rate))) // 64) * 64)
+        cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
+        pieces = min(cus // tiles, T // (2 * warm))        # one workgroup per compute unit; a piece >= 2 warm-ups long
+        if pieces < 2:
+            return None
+        steps = -(-T // pieces)
+        pieces = -(-T // steps)                           # (the last piece may be shorter, never empty)
+        return (pieces, steps, warm) if pieces >= 2 else None
+
+    def _run_time_parallel(self, x, out, h_state, plan, weights, act):
+        """Four launches on the caller's stream, no host round trip: (1) warm-ups -- pieces 1 .. P-1 run ``warm`` steps in
+        front of their cut from a zero state and leave only their final state; (2) all P pieces from those states
+        (piece 0: the caller's); (3) the splice test -- every piece's end state against its successor's warmed-up start,
+        max-abs <= tol (NaN fails) -> a device flag; (4) the sequential layer under ``flag == 0``: it runs, and repairs
+        every row, only if a splice was rejected.  An accepted result differs from the sequential one by at most tol at
+        a cut, contracting from there -- two orders below the encoder's 1e-5."""
+        P, S, W = plan
+        T, N, _ = x.shape
+        R = self.hidden_size
+        w_ih, w_hh, b = weights
+        init = torch.zeros(P, N, R, dtype=torch.float32, device=x.device)
+        if h_state is not None:
+            init[0].copy_(h_state)
+        hip.reservoir_pieces(x[S - W:], w_ih, w_hh, b, self.alpha, act, out, init[1:], W, W, S * x.stride(0), 0,
+                             no_store=True)
+        end = init.clone()
+        hip.reservoir_pieces(x, w_ih, w_hh, b, self.alpha, act, out, end, S, T - (P - 1) * S, S * x.stride(0),
+                             S * out.stride(0))
+        gap = (end[:-1] - init[1:]).abs().amax()
+        tol = tune.get("time_parallel_tol", self.time_parallel_tol, float)
+        flag = (gap <= tol).to(torch.int32).reshape(1)
+        hip.reservoir_pieces(x, w_ih, w_hh, b, self.alpha, act, out, h_state, T, T, 0, 0, pred=(flag, 0))
+        if h_state is not None:
+            h_state.copy_(torch.where(flag.bool(), end[P - 1], h_state))
+        self.last_time_parallel = dict(pieces=P, steps=S, warm=W, flag=flag, gap=gap)
+        return out
 
     def forward(self, x, h):
         """One step (reservoir.py:77-81): a length-1 sequence with initial state h."""
@@ -192,6 +268,16 @@ class Reservoir(nn.Module):
         return out
 
     fused = True                    # set False to force one launch per layer
+
+    def time_parallel(self, T, N, device):
+        """True when every layer of a [T, N, .] sequence runs as time pieces side by side (``ReservoirLayer.
+        time_parallel_plan``): the chain then fills the chip by itself and is an order of magnitude shorter, so the
+        encoder does not pipeline it against the hops."""
+        if self.fused and len(self.reservoir_layers) > 1 and self.hidden_size * len(self.reservoir_layers) <= 256 and \
+                hip.reservoir_fused_supported(self.input_size, self.hidden_size, len(self.reservoir_layers)):
+            return False                                   # (the stacked kernel serves narrow multi-layer reservoirs)
+        return all(l.time_parallel_plan(T, N, self.input_size if i == 0 else self.hidden_size, device) is not None
+                   for i, l in enumerate(self.reservoir_layers))
 
     def produces_col_sums(self, x):
         """True when ``encode_into(..., col_sums=)`` gets the sums from the kernel's registers (the

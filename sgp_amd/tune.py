@@ -9,7 +9,7 @@ Python layer
     exact_plans=lazy|eager  where the split-fp16 hop is the default: build the exact kernels' tile / mix plans only after an
                             admission flag came back 0 (until then the generic CSR kernel sits behind the predicate), or up front
     split_guard=1|0, split_passes=1|0   admission statistics of the split-fp16 hop; long-row operators in passes
-    time_parallel=1|0, time_parallel_warm=384   small graphs, contractive reservoirs: time pieces computed side by side from a
+    time_parallel=1|0, time_parallel_warm=<steps>, time_parallel_tol=1e-6   small graphs, contractive reservoirs: time pieces computed side by side from a
                             warm-up, accepted by a device-side comparison at every splice (0: one sequential chain)
     mix_thr=4               a column goes through the dense 16x16x4 part when >= thr of a block's 4 groups use it
     mix_min_share=0.25      least share of (group, column) pairs in the dense part for the mixed kernel to be chosen

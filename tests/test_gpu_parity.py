@@ -1140,7 +1140,8 @@ def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical():
                              bidirectional=True, alpha_decay=False, global_attr=True)
     ops = enc.sgp_encoder.operators(n, ei, ew)
     x = torch.randn(t, n, 3).cuda()
-    assert enc._overlap_pieces(t, n) == 16 and enc._overlap_pieces(t, 100000) == 1 and enc._overlap_pieces(1000, n) == 1
+    assert enc._overlap_pieces(t, n) == 16 and enc._overlap_pieces(t, 100000) == 1 and enc._overlap_pieces(1000, n) == 8 \
+        and enc._overlap_pieces(100, n) == 1
     out = enc.encode_device(x, ops)
     again = enc.encode_device(x, ops)
     enc.overlap_chunks = 1

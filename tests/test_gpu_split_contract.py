@@ -262,3 +262,54 @@ def test_leaking_rate_outside_the_unit_interval_is_measured():
                             bidirectional=False, alpha_decay=False, global_attr=False)
     assert ok._state_bound() == 1.0
     assert ok._state_bound(torch.zeros(1, 4, 32)) is None              # a state from elsewhere: measured
+
+
+def test_tiny_values_inside_a_large_column_meet_the_documented_absolute_bound(op):
+    """The contract's residue, pinned (round-5 review): one column holds ~1e-9 values on half the graph and O(1) values on
+    the other half.  The column's RMS is large, so the admission test passes and the SPLIT kernel runs; values 2^16
+    below the column's bound are then carried to 2^-38 B ABSOLUTE, not relative.  What is promised and asserted: every
+    result entry within 2^-37 B ||A||_inf (B rounded up to its power of two) + fp32's own relative 2^-21 of the exact
+    value, and the encoder's allclose(1e-5, 1e-5); what is NOT promised: fp32's element-wise relative accuracy on the
+    tiny half (an fp32 product resolves 1e-9 beside 1; here those entries carry up to ~1e-2 relative error)."""
+    torch.manual_seed(11)
+    x = torch.randn(T, N, D)
+    c = 21
+    x[:, :N // 2, c] *= 1e-9
+    y, kernel = default_hop(op, x)
+    assert kernel == "spmm_split"                                # admitted: the column's RMS is ~0.7
+    ref64, cpu32 = products(op, x)
+    yc = y.cpu()
+    assert torch.allclose(yc, ref64.float(), rtol=1e-5, atol=1e-5)
+    check_columns(y, ref64, cpu32)
+    bound = float(x[:, :, c].abs().max())
+    limit = 2.0 ** -37 * bound * op.norm_inf() + 2.0 ** -21 * ref64[:, :, c].abs()
+    err = (yc[:, :, c].double() - ref64[:, :, c]).abs()
+    assert bool((err <= limit).all()), float((err - limit).max())
+    # the residue is real (this is what the bound is about): rows whose neighbours all lie in the tiny half
+    tiny_rows = ref64[:, :, c].abs() < 1e-8
+    assert int(tiny_rows.sum()) > 100
+    rel = (err / ref64[:, :, c].abs().clamp_min(1e-300))[tiny_rows]
+    assert float(rel.max()) < 0.1                                # bounded by 2^-37 B / |value| ...
+    rel32 = ((cpu32[:, :, c].double() - ref64[:, :, c]).abs() / ref64[:, :, c].abs().clamp_min(1e-300))[tiny_rows]
+    assert float(rel32.max()) < 1e-5                             # ... where plain fp32 resolves them
+
+
+def test_streamed_equals_one_pass_to_1e6_with_a_measured_bound():
+    """relu reservoir (no a-priori bound: every hop MEASURES its operand): the per-column scales then depend on the
+    time chunk, so a streamed encoding is no longer bit-identical to a single pass (tanh: a-priori bound 1, identical
+    bits -- tests/test_gpu_parity.py::test_streamed_encoding_equals_single_pass).  Both are fp32-equivalent
+    evaluations of the same products: they agree to 1e-6 of the block's scale (INTEGRATION.md says so)."""
+    torch.manual_seed(12)
+    n, t = 2600, 96
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=9)
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=64, reservoir_layers=1, leaking_rate=.9,
+                             spectral_radius=.5, density=.7, input_scaling=1., receptive_field=3,
+                             bidirectional=False, alpha_decay=False, global_attr=False, reservoir_activation="relu")
+    x = torch.randn(t, n, 3)
+    ops = enc.sgp_encoder.operators(n, ei, ew)
+    full = enc.encode_device(x.cuda(), ops).cpu()
+    assert ops[0].resolved_kernel() == "spmm_split"
+    chunked = enc.encode_streamed(x, ops, 13)
+    scale = float(full.abs().max())
+    assert torch.equal(chunked[:, :, :64], full[:, :, :64])          # the recurrence itself is carried exactly
+    assert float((chunked - full).abs().max()) <= 1e-6 * max(1.0, scale)

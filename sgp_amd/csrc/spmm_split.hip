@@ -499,6 +499,7 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     a.Y = Y; a.yrs = y_row_stride; a.ybs = y_batch_stride;
     a.batch = batch; a.nslice = feat / 16;
     a.xtab = x_tab; a.pred = pr.flag; a.pred_want = pr.want;
+    const bool auto_tc = t_chunk <= 0;
     if (t_chunk <= 0) {
         // time steps per workgroup: long chunks amortise the plan load (A fragments: ~1.6 units' worth of staging per
         // workgroup), short ones fill the last round of the chip.  Cost model: rounds taken / rounds of work x
@@ -517,10 +518,15 @@ extern "C" int sgp_spmm_split_f32(const int32_t* hdr, const int32_t* rowid, cons
     }
     // time-major mapping where one step's source rows (n_cols x feat floats) fit an XCD's L2 beside the result rows
     // streaming out (SGP_TUNE=split_time_major=0|1 overrides; split_tc = time steps per workgroup there)
+    // Measured (profiles/r6/ab_time_major.log, ms per hop, tile-major -> time-major at 16 steps per workgroup): PV-US shape
+    // 100-NN 17.0 -> 15.4, its full graph (8 passes) 110.9 -> 92.8, N = 10 000 3.81 -> 3.62 (64 steps).
     static const long tm_tune = sgp::tune("split_time_major", -1);
     static const long tm_tc = sgp::tune("split_tc", 0);
-    a.time_major = tm_tune >= 0 ? (int)(tm_tune != 0) : 0;
-    if (a.time_major && tm_tc > 0) t_chunk = (int)tm_tc;
+    a.time_major = tm_tune >= 0 ? (int)(tm_tune != 0) : (int)((long long)n_cols * feat * 4 <= (4ll << 20) && n_tiles >= 8);
+    if (a.time_major) {
+        if (tm_tc > 0 && auto_tc) t_chunk = (int)tm_tc;
+        else if (auto_tc && n_tiles <= 32 && t_chunk > 16) t_chunk = 16;       // (few tiles: short chunks keep an XCD's tiles on the same steps)
+    }
     a.t_chunk = t_chunk;
 #ifdef SGP_ABLATION
     static const int abl = (int)sgp::tune("split_abl", 0);

@@ -29,6 +29,8 @@ Library (integers)
                             read (0: one tile after the other)
     res_tail_beside=1       the split-J tail of a large layer runs on a side lane beside the main part (0: after it)
     spmm_chunk=32           time steps per workgroup of the staged exact kernels
+    split_time_major=0|1, split_tc=16   split-fp16 hop: an XCD walks its own TIME chunks over all tiles (default: on where a step's
+                            source rows fit an L2, i.e. n_cols x feat x 4 <= 4 MB) instead of its own tiles over all time
     spmm_variant=1          inner-loop variant of sgp_spmm_tiled_f32
     mix_mode=6, res_cfg=0   launch shapes of sgp_spmm_mix_f32 / sgp_spmm_res_f32
     abl=0                   ablation bits of res / mix (only in builds with -DSGP_ABLATION)

@@ -268,8 +268,7 @@ def test_tiny_values_inside_a_large_column_meet_the_documented_absolute_bound(op
     """The contract's residue, pinned (round-5 review): one column holds ~1e-9 values on half the graph and O(1) values on
     the other half.  The column's RMS is large, so the admission test passes and the SPLIT kernel runs; values 2^16
     below the column's bound are then carried to 2^-38 B ABSOLUTE, not relative.  What is promised and asserted: every
-    result entry within 2^-37 B ||A||_inf (B rounded up to its power of two) + fp32's own relative 2^-21 of the exact
-    value, and the encoder's allclose(1e-5, 1e-5); what is NOT promised: fp32's element-wise relative accuracy on the
+    result entry within 2^-37 B ||A||_inf (B rounded up to its power of two) + fp32's own 2^-21 sum_j |a_ij x_j|, and the encoder's allclose(1e-5, 1e-5); what is NOT promised: fp32's element-wise relative accuracy on the
     tiny half (an fp32 product resolves 1e-9 beside 1; here those entries carry up to ~1e-2 relative error)."""
     torch.manual_seed(11)
     x = torch.randn(T, N, D)
@@ -282,7 +281,10 @@ def test_tiny_values_inside_a_large_column_meet_the_documented_absolute_bound(op
     assert torch.allclose(yc, ref64.float(), rtol=1e-5, atol=1e-5)
     check_columns(y, ref64, cpu32)
     bound = float(x[:, :, c].abs().max())
-    limit = 2.0 ** -37 * bound * op.norm_inf() + 2.0 ** -21 * ref64[:, :, c].abs()
+    # (fp32's own term is relative to sum_j |a_ij| |x_j|, not to the -- possibly cancelled -- result)
+    a_abs = torch.sparse_csr_tensor(op.rowptr.long(), op.col.long(), op.val.double().abs(), (op.num_nodes, op.num_cols))
+    mag = torch.stack([a_abs @ x[b, :, c:c + 1].double().abs() for b in range(T)])[:, :, 0]
+    limit = 2.0 ** -37 * bound * op.norm_inf() + 2.0 ** -21 * mag
     err = (yc[:, :, c].double() - ref64[:, :, c]).abs()
     assert bool((err <= limit).all()), float((err - limit).max())
     # the residue is real (this is what the bound is about): rows whose neighbours all lie in the tiny half

@@ -43,8 +43,8 @@ extern "C" {
 #endif
 
 /* 3 (round 6): the launch predicate became the explicit trailing (pred, run_if) pair of every sgp_spmm_*_f32 entry
- * (sgp_launch_predicate removed); host-side planner sgp_split_plan_deal / sgp_split_plan_fill and the time-piece
- * reservoir entry sgp_reservoir_pieces_f32 added.
+ * (sgp_launch_predicate removed); host-side planner sgp_split_plan_deal / sgp_split_plan_fill, the time-piece
+ * reservoir entry sgp_reservoir_pieces_f32 and the wide split hop sgp_spmm_split_wide_f32 added.
  * 2 (round 5): sgp_spmm_split_f32 takes per-column scale tables and a per-row plan array; sgp_col_stats_f32,
  * sgp_split_prepare_f32, sgp_launch_predicate added; round 4 had already removed sgp_spmm_mfma / pipe / blk_*, widened
  * sgp_spmm_colblock_f32 by the halo arguments and grown sgp_reservoir_workspace_bytes (bf16-piece fragments). */
@@ -271,6 +271,25 @@ int32_t sgp_spmm_split_max_union(void);
 int32_t sgp_spmm_split_waves(void);
 int32_t sgp_spmm_split_rows_per_wave(void);
 int32_t sgp_spmm_split_max_feat(void);
+
+/* The same kernel in its WIDE form (csrc/spmm_split_wide.hip): 8 waves x 16 rows x 14 chunks -- 448 columns per wave, two
+ * waves per SIMD.  For operators whose rows exceed the standard form's 224 columns (the reference's full large-scale
+ * graphs, config/largescale/sgp_pv.yaml / sgp_cer.yaml with experiments/run_largescale_sgp.py:167-170: ~740 / ~495
+ * entries per row): half as many accumulating passes and less than half the staged rows per result row.  Same arguments,
+ * array formats and error model as sgp_spmm_split_f32, with W = sgp_spmm_split_wide_waves(), chunks =
+ * sgp_spmm_split_wide_chunks(), max_union = sgp_spmm_split_wide_max_union(). */
+int sgp_spmm_split_wide_f32(const int32_t* hdr, const int32_t* rowid, const int32_t* ucol, const void* afr,
+                            const int32_t* adr, const float* rinv, int32_t n_tiles,
+                            const float* X, int64_t x_row_stride, int64_t x_batch_stride,
+                            const float* X_halo, int64_t xh_row_stride, int64_t xh_batch_stride, int32_t n_own,
+                            float* Y, int64_t y_row_stride, int64_t y_batch_stride,
+                            int32_t n_rows, int32_t n_cols, int32_t batch, int32_t feat,
+                            const float* x_tab, int32_t accumulate, int32_t t_chunk, const int32_t* pred, int32_t run_if, sgp_stream_t stream);
+int32_t sgp_spmm_split_wide_chunks(void);
+int32_t sgp_spmm_split_wide_max_union(void);
+int32_t sgp_spmm_split_wide_waves(void);
+int32_t sgp_spmm_split_wide_rows_per_wave(void);
+int32_t sgp_spmm_split_wide_max_feat(void);
 
 /* Host-side planner of sgp_spmm_split_f32 (csrc/plan_split.hip; HOST pointers, no GPU needed; the encoder builds the
  * plan once per graph in front of `x = adj @ x`, lib/sgp_preprocessing.py:188-203).

@@ -267,10 +267,12 @@ class ShiftOperator:
             if self.nnz() > 0:
                 from . import hip, plancache
                 lib = hip.load()
-                lim = dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
-                           max_union=lib.sgp_spmm_split_max_union(), rows_per_wave=lib.sgp_spmm_split_rows_per_wave())
-                plan = plancache.fetch(self, "split", (sorted(lim.items()), tune.get("split_passes", 1, int)),
-                                       lambda: self._build_split_plan(lim))
+                lim, wide = hip.split_limits(), hip.split_limits(wide=True)
+                if tune.get("split_wide", 1, int) == 0:
+                    wide = None
+                plan = plancache.fetch(self, "split", (sorted(lim.items()), wide and sorted(wide.items()),
+                                                       tune.get("split_passes", 1, int)),
+                                       lambda: self._build_split_plan(lim, wide))
                 if isinstance(plan, list):
                     plan = SplitPasses(p.to(device) for p in plan)
                 elif plan is not None:
@@ -278,8 +280,10 @@ class ShiftOperator:
             self._plans[key] = plan
         return self._plans[key]
 
-    def _build_split_plan(self, lim):
-        """Host side of ``split_plan``: a SplitPlan, a list of them (long rows, one per pass) or None."""
+    def _build_split_plan(self, lim, wide=None):
+        """Host side of ``split_plan``: a SplitPlan, a list of them (long rows, one per pass) or None.  ``wide``: limits of
+        the kernel's wide form (448 instead of 224 columns per wave at half the waves): long-row operators are planned
+        for it -- half the passes, less than half the staged rows per result row."""
         from . import splitplan
         args = (self.rowptr.numpy(), self.col.numpy(), self.val.numpy(), self.num_nodes, self.num_cols)
         plan = splitplan.build_split_plan(*args, **lim)
@@ -296,11 +300,13 @@ class ShiftOperator:
                                  plan.stats["staged_per_row"] > 8):
             plan = None
         if plan is None and self.max_degree() > 32 * lim["chunks"] and tune.get("split_passes", 1, int) != 0:
-            # long rows: several passes over column segments, accumulated in place
-            passes = splitplan.build_split_passes(*args, max_passes=12, **lim)
+            # long rows: several passes over column segments, accumulated in place (the wide form where the library has it)
+            passes = splitplan.build_split_passes(*args, max_passes=12, **(wide or lim))
             if passes is not None and passes[0].stats["rows_per_wave"] >= 0.5 * lim["rows_per_wave"] and \
                     passes[0].stats["staged_per_row"] <= 8:
                 plan = list(passes)
+            elif wide is not None:                               # (the wide deal did not work out: the standard passes)
+                return self._build_split_plan(lim, None)
         return plan
 
     def prepare(self, feat, device, halo=False):

@@ -121,6 +121,14 @@ SIGNATURES = {
                                           c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
     "sgp_col_stats_f32": (ctypes.c_int, [c_p, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_p, c_p]),
     "sgp_split_prepare_f32": (ctypes.c_int, [c_p, c_f64, c_f64, c_i32, c_p, c_f32, c_f32, c_i32, c_p, c_p, c_p, c_p]),
+    "sgp_spmm_split_wide_f32": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_p, c_i64, c_i64,
+                                               c_p, c_i64, c_i64, c_i32, c_p, c_i64, c_i64,
+                                               c_i32, c_i32, c_i32, c_i32, c_p, c_i32, c_i32, c_p, c_i32, c_p]),
+    "sgp_spmm_split_wide_chunks": (c_i32, []),
+    "sgp_spmm_split_wide_max_union": (c_i32, []),
+    "sgp_spmm_split_wide_waves": (c_i32, []),
+    "sgp_spmm_split_wide_rows_per_wave": (c_i32, []),
+    "sgp_spmm_split_wide_max_feat": (c_i32, []),
     "sgp_spmm_split_chunks": (c_i32, []),
     "sgp_spmm_split_max_union": (c_i32, []),
     "sgp_spmm_split_waves": (c_i32, []),
@@ -499,7 +507,10 @@ def spmm_split(plan, x, y, profile, t_chunk=0, halo=None, n_own=None, predicated
     plans = plan if isinstance(plan, (list, tuple)) else [plan]
     pr = _pred((profile.flag, 1) if predicated else None)
     for p in plans:                                   # (several passes: an operator whose long rows were cut into column segments)
-        _check(lib.sgp_spmm_split_f32(
+        # the plan's geometry names its kernel: 16 waves x 7 chunks (standard) or 8 x 14 (wide: long rows)
+        entry = lib.sgp_spmm_split_wide_f32 if p.afr.shape[1] == lib.sgp_spmm_split_wide_waves() and \
+            p.afr.shape[2] == lib.sgp_spmm_split_wide_chunks() else lib.sgp_spmm_split_f32
+        _check(entry(
             p.hdr.data_ptr(), p.rowid.data_ptr(), p.ucol.data_ptr(), p.afr.data_ptr(), p.adr.data_ptr(),
             p.rinv.data_ptr(), p.n_tiles,
             xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, p.n_rows, p.n_cols, x.shape[0], x.shape[2],
@@ -523,6 +534,16 @@ def spmm_colblock(plan, x, y, halo=None, n_own=None, pred=None):
         plan.entries.data_ptr(), plan.segptr.data_ptr(), plan.wg_row0.data_ptr(), plan.n_wg, plan.n_blocks,
         xp, xrs, xbs, hp, hrs, hbs, n_own, yp, yrs, ybs, plan.n_rows, plan.n_cols, x.shape[0], x.shape[2], *_pred(pred),
         _stream(x)), "sgp_spmm_colblock_f32")
+
+
+def split_limits(wide=False):
+    """Plan limits of the split-fp16 hop: the standard form (16 waves x 7 chunks) or the wide one (8 x 14)."""
+    lib = load()
+    if wide:
+        return dict(waves=lib.sgp_spmm_split_wide_waves(), chunks=lib.sgp_spmm_split_wide_chunks(),
+                    max_union=lib.sgp_spmm_split_wide_max_union(), rows_per_wave=lib.sgp_spmm_split_wide_rows_per_wave())
+    return dict(waves=lib.sgp_spmm_split_waves(), chunks=lib.sgp_spmm_split_chunks(),
+                max_union=lib.sgp_spmm_split_max_union(), rows_per_wave=lib.sgp_spmm_split_rows_per_wave())
 
 
 def tiled_limits(feat):

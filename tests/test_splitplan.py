@@ -155,3 +155,36 @@ def test_plan_cache_round_trip(tmp_path, monkeypatch):
         if f.name.startswith("split-"):
             f.write_bytes(f.read_bytes()[:100])
     same_plan(ShiftOperator.from_edges(ei, ew, n).split_plan(cpu), a)
+
+
+WIDE = dict(waves=8, chunks=14, max_union=768, rows_per_wave=16)
+
+
+@pytest.mark.parametrize("name", ["knn_dense", "ragged", "duplicates"])
+def test_native_planner_equals_numpy_planner_in_the_wide_geometry(name):
+    """The wide form of the split hop (8 waves x 14 chunks: csrc/spmm_split_wide.hip) takes the same plan format."""
+    rowptr, col, val = CASES[name]()
+    n_rows, n_cols = rowptr.size - 1, int(col.max()) + 1
+    with np.errstate(over="ignore", under="ignore"):
+        ref = splitplan.build_split_plan_numpy(rowptr, col, val, n_rows, n_cols, **WIDE)
+        got = splitplan.build_split_plan(rowptr, col, val, n_rows, n_cols, **WIDE)
+    same_plan(got, ref)
+    assert tuple(got.afr.shape[1:3]) == (8, 14)
+
+
+def test_long_row_operators_are_planned_for_the_wide_kernel():
+    """Rows of ~400 entries (beyond the standard form's 224 columns per wave): the operator's plan is a list of WIDE
+    passes, fewer than the standard geometry needs, and encodes the operator."""
+    n = 1400
+    ei, ew, _ = synthetic.threshold_graph(n, 330, seed=4)
+    op = ShiftOperator.from_edges(ei, ew, n)
+    rowptr, col, val = op.rowptr.numpy().astype(np.int64), op.col.numpy().astype(np.int64), op.val.numpy()
+    assert op.max_degree() > 224
+    plan = op.split_plan(torch.device("cpu"))
+    assert plan is not None and all(tuple(p.afr.shape[1:3]) == (8, 14) for p in plan)
+    std = splitplan.build_split_passes(rowptr, col, val, n, n, **LIM)
+    assert len(plan) < len(std)
+    dense = np.zeros((n, n))
+    np.add.at(dense, (np.repeat(np.arange(n), np.diff(rowptr)), col), val.astype(np.float64))
+    got = sum(splitplan.plan_matrix(p, n, n) for p in plan)
+    assert np.abs(got - dense).max() <= 2.0 ** -21 * np.abs(dense).max()

@@ -300,7 +300,13 @@ class ShiftOperator:
                                  plan.stats["staged_per_row"] > 8):
             plan = None
         if plan is None and self.max_degree() > 32 * lim["chunks"] and tune.get("split_passes", 1, int) != 0:
-            # long rows: several passes over column segments, accumulated in place (the wide form where the library has it)
+            # long rows: several passes over column segments, accumulated in place -- in the kernel's WIDE form (448
+            # columns per wave, two waves per SIMD) where most rows are long (the full large-scale graphs), in the
+            # standard form where a few hub rows sit in a graph of short ones (every row's first segment then runs at
+            # the standard form's rate)
+            deg = (self.rowptr[1:] - self.rowptr[:-1])
+            if wide is not None and float((deg > 32 * lim["chunks"]).float().mean()) < 0.5:
+                wide = None
             passes = splitplan.build_split_passes(*args, max_passes=12, **(wide or lim))
             if passes is not None and passes[0].stats["rows_per_wave"] >= 0.5 * lim["rows_per_wave"] and \
                     passes[0].stats["staged_per_row"] <= 8:

@@ -136,6 +136,7 @@ class SGPEncoder(nn.Module):
     # Round 5 (chain 0.76 us per step, hops 33 of the 39 ms beside it): 8 pieces 49.0 ms, 12: 45.2, 16: 45.0, 24: 48.3 -- the tail is the last piece's hops.
     overlap_tiles = 128
     overlap_chunks = 16
+    overlap_chunks_time_parallel = 1   # time chunks of that pipeline when the reservoir runs as time pieces (SGP_TUNE=overlap_chunks_tp)
     overlap_masked_tiles = 32      # the chain gets its own compute units up to this many node tiles (hip.cu_masked_streams)
 
     def _overlap_pieces(self, T, N):
@@ -177,8 +178,13 @@ class SGPEncoder(nn.Module):
         if out is None:
             out = torch.empty(T, N, self.output_size, dtype=torch.float32, device=x.device)
         chunks = self._overlap_pieces(T, N)
-        if chunks > 1 and self.reservoir.time_parallel(T, N, x.device):
-            chunks = 1                                        # the reservoir runs as time pieces on the whole chip, then the hops
+        time_parallel = chunks > 1 and self.reservoir.time_parallel(T, N, x.device)
+        if time_parallel:
+            # the reservoir runs as time pieces on the whole chip: few, long time chunks (the chain of chunk c + 1 under
+            # the hops of chunk c), ordinary streams -- the chain is no longer a handful of workgroups to fence off
+            chunks = max(1, min(tune.get("overlap_chunks_tp", self.overlap_chunks_time_parallel, int), chunks))
+            while chunks > 1 and not self.reservoir.time_parallel(T // chunks, N, x.device):
+                chunks //= 2
         x_bound = self._state_bound(state)
         # global_attr: the column sums of the states come from the reservoir kernel where it has them
         # in registers (fused stacked kernel); the other kernels keep the fused mean + broadcast pass
@@ -203,7 +209,7 @@ class SGPEncoder(nn.Module):
         # kernels between two pieces of the chain (weight packing) no longer queue behind hop workgroups (65 -> 5 us
         # each; PEMS-BAY shape 51.2 -> 48.6 ms per pass).  Up to 32 tiles.
         tiles = (N + 15) // 16
-        if tiles <= self.overlap_masked_tiles and tune.get("overlap_cu_mask", 1, int):
+        if tiles <= self.overlap_masked_tiles and tune.get("overlap_cu_mask", 1, int) and not time_parallel:
             pair = hip.cu_masked_streams(x.device, (tiles + 7) // 8 * 8)
             if pair is not None:
                 chain, side = pair

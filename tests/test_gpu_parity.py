@@ -1127,11 +1127,13 @@ def test_streamed_encoding_equals_single_pass():
     assert not chunked.is_cuda and torch.equal(chunked, full)
 
 
-def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical():
+def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical(monkeypatch):
     """Small graphs with hop-heavy settings (PEMS-BAY shape: K = 4, both directions, global block): the
     hops of one time piece run on a second stream under the reservoir of the next (SGPEncoder.
     encode_device).  Same kernels on the same data: identical bits, also across repeated calls and
-    with a state carried by the caller."""
+    with a state carried by the caller.  (The reservoir as ONE chain: its time pieces -- round 6, accepted to 1e-6 at
+    every splice, tests/test_gpu_time_parallel.py -- are not bit-identical to it and are switched off here.)"""
+    monkeypatch.setenv("SGP_TUNE", "time_parallel=0")
     torch.manual_seed(21)
     n, t = 325, 1100
     ei, ew = synthetic.sparse_traffic_graph(n, 2369, seed=2)
@@ -1163,16 +1165,8 @@ def test_small_graph_overlap_of_reservoir_and_hops_is_bit_identical():
     ei2, ew2 = synthetic.sparse_traffic_graph(207, 1515, seed=3)
     ops2 = enc2.sgp_encoder.operators(207, ei2, ew2)
     cut = enc2.encode_device(x2, ops2)
-    import os
-    saved = os.environ.get("SGP_TUNE")
-    os.environ["SGP_TUNE"] = "overlap_chunks=1" + ("," + saved if saved else "")
-    try:
-        whole = enc2.encode_device(x2, ops2)
-    finally:
-        if saved is None:
-            del os.environ["SGP_TUNE"]
-        else:
-            os.environ["SGP_TUNE"] = saved
+    monkeypatch.setenv("SGP_TUNE", "time_parallel=0,overlap_chunks=1")
+    whole = enc2.encode_device(x2, ops2)
     assert torch.equal(cut, whole)
 
 

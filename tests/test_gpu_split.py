@@ -170,15 +170,17 @@ def test_split_is_not_chosen_where_it_cannot_serve():
 def test_split_long_rows_full_graph_shapes(n, deg):
     """The reference's FULL large-scale graphs (config/largescale/sgp_pv.yaml with adj_knn=None,
     experiments/run_largescale_sgp.py:167-170: ~740 entries per row on 5 016 nodes; CER-En ~495): every group of 16
-    rows has its column union cut into segments of one wave's budget, one launch per segment, results accumulated in
-    place.  Parity against the dense fp64 product, per column, and against the CPU fp32 product."""
+    rows has its column union cut into segments of one wave's budget (the kernel's wide form: 448 columns), one launch per
+    segment, results accumulated in place; SGP_TUNE=split_wide=0: the standard form's 224-column segments.  Parity against the dense fp64 product, per column, and against the CPU fp32 product."""
     torch.manual_seed(n)
     ei, ew, _ = synthetic.threshold_graph(n, deg, seed=1)
     op = graph.ShiftOperator.from_edges(ei, ew, n)
     assert op.max_degree() > 256
     passes = op.split_plan(torch.device("cuda"))
     assert isinstance(passes, list) and len(passes) >= 3
-    assert passes[0].stats["rows_per_wave"] > 12 and passes[0].stats["staged_per_row"] < 5
+    # most rows are long: the WIDE form (8 waves x 448 columns per wave) -- half the passes of the standard form
+    assert all(tuple(p.afr.shape[1:3]) == (8, 14) for p in passes) and len(passes) <= 5
+    assert passes[0].stats["rows_per_wave"] > 12 and passes[0].stats["staged_per_row"] < 8
     t, feat = 5, 128
     out = torch.randn(t, n, 3 * feat, device="cuda")
     out[:, :, :feat] = torch.tanh(out[:, :, :feat])

@@ -291,9 +291,9 @@ def test_tiny_values_inside_a_large_column_meet_the_documented_absolute_bound(op
     tiny_rows = ref64[:, :, c].abs() < 1e-8
     assert int(tiny_rows.sum()) > 100
     rel = (err / ref64[:, :, c].abs().clamp_min(1e-300))[tiny_rows]
-    assert float(rel.max()) < 0.1                                # bounded by 2^-37 B / |value| ...
+    assert 1e-4 < float(rel.median()) < 0.1                      # ~1e-2 RELATIVE on such entries (2^-37 B / |value|) ...
     rel32 = ((cpu32[:, :, c].double() - ref64[:, :, c]).abs() / ref64[:, :, c].abs().clamp_min(1e-300))[tiny_rows]
-    assert float(rel32.max()) < 1e-5                             # ... where plain fp32 resolves them
+    assert float(rel32.median()) < 1e-6                          # ... where plain fp32 resolves them
 
 
 def test_streamed_equals_one_pass_to_1e6_with_a_measured_bound():

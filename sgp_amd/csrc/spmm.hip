@@ -41,15 +41,12 @@ struct Src {                      // where column c of step b lives
 // LPR lanes cover one source row chunk of 4*LPR floats; G = 64/LPR edges are in flight per
 // wave instruction; TB time steps share every (col, val) fetch.
 template <int LPR, int TB>
-__global__ __launch_bounds__(256) void spmm_csr_rows(
+__device__ __forceinline__ void csr_rows_body(
         const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-        Src src, float* __restrict__ Y, long long yrs, long long ybs,
-        int n_rows, int batch, int feat) {
+        const Src& src, float* __restrict__ Y, long long yrs, long long ybs,
+        int batch, int feat, int row, int b0) {
     constexpr int G = kWave / LPR;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= n_rows || src.skip()) return;
-    const int b0 = blockIdx.y * TB;
     const int f0 = blockIdx.z * (4 * LPR) + (lane % LPR) * 4;
     const int g = lane / LPR;
     const bool fok = f0 < feat;
@@ -87,6 +84,34 @@ __global__ __launch_bounds__(256) void spmm_csr_rows(
         if (fok && b0 + i < batch && g == (i % G))
             st4(Y + (long long)(b0 + i) * ybs + (long long)row * yrs + f0, acc[i]);
     }
+}
+
+template <int LPR, int TB>
+__global__ __launch_bounds__(256) void spmm_csr_rows(
+        const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+        Src src, float* __restrict__ Y, long long yrs, long long ybs,
+        int n_rows, int batch, int feat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= n_rows || src.skip()) return;
+    csr_rows_body<LPR, TB>(rowptr, col, val, src, Y, yrs, ybs, batch, feat, row, blockIdx.y * TB);
+}
+
+// The same product under a launch predicate: a BOUNDED grid that strides over (row block, batch block).  A predicated
+// launch that does not run still dispatches every workgroup to its first instruction -- 6.4 million of them for the
+// direct form on the target line (N = 100 000, T = 1024): 1.43 ms per skipped launch, measured behind every split hop
+// when this kernel became the default fallback (round 6).  2048 x 8 workgroups exit in microseconds.
+template <int LPR, int TB>
+__global__ __launch_bounds__(256) void spmm_csr_rows_strided(
+        const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+        Src src, float* __restrict__ Y, long long yrs, long long ybs,
+        int n_rows, int batch, int feat) {
+    if (src.skip()) return;
+    const int n_rb = (n_rows + 3) / 4, n_bb = (batch + TB - 1) / TB;
+    for (int bb = blockIdx.y; bb < n_bb; bb += gridDim.y)
+        for (int rb = blockIdx.x; rb < n_rb; rb += gridDim.x) {
+            const int row = rb * 4 + (threadIdx.x >> 6);
+            if (row < n_rows) csr_rows_body<LPR, TB>(rowptr, col, val, src, Y, yrs, ybs, batch, feat, row, bb * TB);
+        }
 }
 
 __global__ __launch_bounds__(256) void spmm_csr_scalar(
@@ -456,9 +481,17 @@ int sgp_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val
     constexpr int TB = 4;
     const unsigned gy = (batch + TB - 1) / TB;
     SGP_REQUIRE(gy <= 65535, "sgp_spmm_csr_f32: batch too large for one launch (chunk it)");
+    const bool bounded = pr.flag != nullptr;       // predicated: the grid a skipped launch must retire stays small
 #define SGP_ROWS(LPR)                                                                          \
-    hipLaunchKernelGGL((spmm_csr_rows<LPR, TB>), dim3(gx, gy, (feat + 4 * LPR - 1) / (4 * LPR)), \
-                       dim3(256), 0, s, rowptr, col, val, src, Y, yrs, ybs, n_rows, batch, feat)
+    do {                                                                                       \
+        if (bounded)                                                                           \
+            hipLaunchKernelGGL((spmm_csr_rows_strided<LPR, TB>),                               \
+                               dim3(gx < 2048u ? gx : 2048u, gy < 8u ? gy : 8u, (feat + 4 * LPR - 1) / (4 * LPR)), \
+                               dim3(256), 0, s, rowptr, col, val, src, Y, yrs, ybs, n_rows, batch, feat);          \
+        else                                                                                   \
+            hipLaunchKernelGGL((spmm_csr_rows<LPR, TB>), dim3(gx, gy, (feat + 4 * LPR - 1) / (4 * LPR)), \
+                               dim3(256), 0, s, rowptr, col, val, src, Y, yrs, ybs, n_rows, batch, feat);  \
+    } while (0)
     if (feat >= 256 || feat % 256 == 0) SGP_ROWS(64);
     else if (feat > 64) SGP_ROWS(32);
     else if (feat > 32) SGP_ROWS(16);

@@ -315,3 +315,35 @@ def test_streamed_equals_one_pass_to_1e6_with_a_measured_bound():
     scale = float(full.abs().max())
     assert torch.equal(chunked[:, :, :64], full[:, :, :64])          # the recurrence itself is carried exactly
     assert float((chunked - full).abs().max()) <= 1e-6 * max(1.0, scale)
+
+
+def test_exact_plans_are_built_only_after_a_flag_asked_for_them():
+    """Round 6: where the split hop is the default, the exact kernels' tile / mix plans (16 s of host work on the target
+    graph) are NOT built up front -- the generic CSR kernel sits behind the predicate.  A rejected operand is therefore
+    computed by the CSR kernel the first time; the flag, copied to pinned memory behind the launch and read at a later
+    call without a synchronisation, then makes the operator plan its exact kernels, which serve from there on."""
+    ei, ew, _ = synthetic.knn_graph(N, K, seed=7)
+    op = graph.ShiftOperator.from_edges(ei, ew, N)
+    torch.manual_seed(5)
+    good = torch.randn(T, N, D)
+    bad = good.clone()
+    bad[:, :, 9] *= 1e-9
+    bad[:, ::1300, 9] = 1.0                                             # a column hidden under two outliers: refused
+    ref64, cpu32 = products(op, bad)
+    y, kernel = default_hop(op, good)
+    assert kernel == "spmm_split" and not any(k[0] is True for k in op._plans if isinstance(k, tuple) and len(k) == 2)
+    assert op.prepare(D, torch.device("cuda"))[0] == "split"
+    xg = bad.cuda()
+    y1 = torch.full_like(xg, float("nan"))
+    op.propagate(xg, y1)
+    assert op.last_exact_kernel == "spmm_csr_rows" and not op._exact_seen
+    torch.cuda.synchronize()
+    y2 = torch.full_like(xg, float("nan"))
+    op.propagate(xg, y2)                                                # the poll at the top of this call reads the flag ...
+    assert op._exact_seen and op.last_exact_kernel in ("spmm_mix", "spmm_res", "spmm_tiled")   # ... and the planned kernels serve
+    assert op.resolved_kernel() == op.last_exact_kernel
+    for y in (y1, y2):
+        check_columns(y, ref64, cpu32)
+    # an accepted operand afterwards still takes the split kernel
+    y3, kernel = default_hop(op, good)
+    assert kernel == "spmm_split"

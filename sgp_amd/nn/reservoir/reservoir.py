@@ -121,6 +121,7 @@ class ReservoirLayer(nn.Module):
     # time_parallel_probe.log) -- the distance of either from the fp64 trajectory is 5e-7.  1e-6 = 2.5x that floor,
     # a tenth of the encoder's 1e-5.
     time_parallel_tol = 1e-6
+    time_parallel_wgs_per_cu = 1  # piece workgroups per compute unit (SGP_TUNE=time_parallel_wgs)
 
     def time_parallel_plan(self, T, N, F, device, act=None):
         """``(pieces, steps per piece, warm-up steps)`` when this layer's sequence may be cut into time pieces that run
@@ -144,7 +145,8 @@ class ReservoirLayer(nn.Module):
                 return None                               # nominally not contractive (or so slowly that no warm-up pays)
             warm = min(4096, -(-int(np.ceil(np.log(1e-7) / np.log(rate))) // 64) * 64)
         cus = torch.cuda.get_device_properties(device).multi_processor_count if torch.cuda.is_available() else 256
-        pieces = min(cus // tiles, T // (2 * warm))        # one workgroup per compute unit; a piece >= 2 warm-ups long
+        per_cu = tune.get("time_parallel_wgs", self.time_parallel_wgs_per_cu, int)
+        pieces = min(per_cu * cus // tiles, T // (2 * warm))   # workgroups per compute unit; a piece >= 2 warm-ups long
         if pieces < 2:
             return None
         steps = -(-T // pieces)

@@ -389,8 +389,9 @@ class ShiftOperator:
         # (the tile plan of the exact kernels is built further down, only on the paths that use it: where the split-fp16
         # hop is the default the exact kernels sit behind a predicate that admits them on no shipped configuration, and
         # their plans -- 16 s of host work on the target graph -- are built the first time a flag shows they ran)
-        lazy_exact = force is None and tune.get("exact_plans", "lazy") != "eager" and not self._exact_seen and \
-            self.split_eligible(x, y, halo)
+        bound_unusable = isinstance(x_bound, (int, float)) and x_bound != 0 and not (0 < x_bound < float("inf"))
+        lazy_exact = force is None and not bound_unusable and tune.get("exact_plans", "lazy") != "eager" and \
+            not self._exact_seen and self.split_eligible(x, y, halo)
         plan = None if force in ("csr", "colblock", "split") or lazy_exact else \
             self.tile_plan(x.shape[2], x.device, tall=force in (None, "tiled"))
         # the LDS-staged kernels address rows with 32-bit element offsets (SGP_REQUIRE in csrc: own * xrs,

@@ -188,3 +188,24 @@ def test_long_row_operators_are_planned_for_the_wide_kernel():
     np.add.at(dense, (np.repeat(np.arange(n), np.diff(rowptr)), col), val.astype(np.float64))
     got = sum(splitplan.plan_matrix(p, n, n) for p in plan)
     assert np.abs(got - dense).max() <= 2.0 ** -21 * np.abs(dense).max()
+
+
+def test_prepare_builds_only_what_the_default_dispatch_runs(monkeypatch):
+    """``ShiftOperator.prepare``: where the split hop is the default, the split plan and the device CSR -- not the exact
+    kernels' tile / mix plans (round-5 review: 12.7 + 3.3 s on the target graph for kernels behind a predicate that is 0 on
+    every shipped configuration); small graphs and SGP_TUNE=hop=exact / exact_plans=eager get the staged kernels' plans."""
+    monkeypatch.delenv("SGP_TUNE", raising=False)
+    cpu = torch.device("cpu")
+    ei, ew, _ = synthetic.knn_graph(2600, 30, seed=2)
+    op = ShiftOperator.from_edges(ei, ew, 2600)
+    made = op.prepare(64, cpu)
+    assert made[0] == "split" and made[1].startswith("csr") and len(made) == 2
+    assert ("split", "cpu") in op._plans and (True, "cpu") not in op._plans
+    monkeypatch.setenv("SGP_TUNE", "exact_plans=eager")
+    assert ShiftOperator.from_edges(ei, ew, 2600).prepare(64, cpu)[:2] == ["split", "tile"]
+    monkeypatch.setenv("SGP_TUNE", "hop=exact")
+    assert ShiftOperator.from_edges(ei, ew, 2600).prepare(64, cpu)[0] == "tile"
+    monkeypatch.delenv("SGP_TUNE")
+    ei2, ew2 = synthetic.sparse_traffic_graph(325, 2369, seed=1)
+    assert ShiftOperator.from_edges(ei2, ew2, 325).prepare(128, cpu) == ["tile"]        # traffic-sized: the tall-tile VALU kernel
+    assert ShiftOperator.from_edges(ei, ew, 2600).prepare(20, cpu) == ["csr"]             # a width no staged kernel serves

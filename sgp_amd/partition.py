@@ -388,6 +388,8 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
     if pieces <= 1 or not x.is_cuda:
         sums = torch.empty(T, d_h, dtype=torch.float32, device=x.device) if want_sums else None
         reservoir.encode_into(x, out[:, :, :d_h], state, col_sums=sums)
+        if bound is not None and state is not None:
+            hip.mark_unit_bounded(state)
         return spatial.encode_into(out, d_h, col_sums=sums, x_bound=bound)
     if state is None:
         state = torch.zeros(len(reservoir.reservoir_layers), x.shape[1], reservoir.hidden_size,
@@ -413,6 +415,8 @@ def encode_partitioned(reservoir, spatial: "PartitionedSpatial", x, out, state=N
         spatial.encode_into(out[t0:t1], d_h, col_sums=sums, x_bound=bound)
     for t in (x, out, state):
         t.record_stream(side)
+    if bound is not None:
+        hip.mark_unit_bounded(state)                        # (carried on to the caller's next time chunk)
     return out
 
 

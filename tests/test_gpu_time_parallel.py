@@ -116,3 +116,19 @@ def test_encoder_with_time_pieces_meets_the_oracle_through_the_default_call():
     layers = [dict(w_ih=l.w_ih.data, w_hh=l.w_hh.data, b_ih=l.b_ih.data, alpha=float(l.alpha)) for l in enc.reservoir.reservoir_layers]
     ref = O.sgp_encoder_forward(x, ei, ew, layers, 2, bidirectional=True, global_attr=True, sparse=True)
     assert torch.allclose(y, ref, rtol=1e-5, atol=1e-5), float((y - ref).abs().max())
+
+
+def test_the_unit_bound_mark_survives_the_time_pieces():
+    """The pieces hand the caller's carried state back through an in-place copy (a version bump): a state that was marked
+    as inside [-1, 1] stays marked -- the next time chunk of a streamed encoding keeps its a-priori bound instead of
+    measuring one."""
+    res, layer = _layer(64)
+    n, t = 207, 6000
+    x = torch.randn(t, n, 3, device="cuda")
+    st = hip.mark_unit_bounded(torch.zeros(n, 64, device="cuda"))
+    out = torch.empty(t, n, 64, device="cuda")
+    layer.run_sequence(x, out, st)
+    assert layer.last_time_parallel is not None and hip.is_unit_bounded(st)
+    raw = torch.zeros(n, 64, device="cuda")                    # an unmarked state stays unmarked
+    layer.run_sequence(x, out, raw)
+    assert not hip.is_unit_bounded(raw)

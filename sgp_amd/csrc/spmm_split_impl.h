@@ -80,7 +80,7 @@ static_assert(NLD <= 7 && NBUF * BUF + 2 * MAXFEAT * 4 <= 160 * 1024, "three buf
 #define SGP_SPLIT_RING 3
 #endif
 constexpr int RING = SGP_SPLIT_RING;         // operand registers: the chunk being multiplied + RING - 1 requested ahead
-static_assert(RING == 2 || RING == 3, "one or two chunks of operands in flight");
+static_assert(RING >= 2 && RING <= 4, "one to three chunks of operands in flight");
 
 // LDS operations the conversion issues behind the MFMAs of chunk c (scale + piece 0 | write 2, read 1 | ... | write 2)
 constexpr int conv_ops(int c) { return c == CR ? 2 : (c > CR && c < CR + NLD ? 3 : (c == CR + NLD ? 2 : 0)); }
@@ -99,7 +99,10 @@ constexpr int lgkm_behind(int c, bool conv) {
     if (conv) for (int j = (c - (RING - 1) > 0 ? c - (RING - 1) : 0); j < c; ++j) n += conv_ops(j);
     return n;
 }
-static_assert(lgkm_behind(NCH - 1, true) <= 15 && lgkm_behind(CR + 1, true) <= 15 && lgkm_behind(CR + 2, true) <= 15, "lgkmcnt holds 15");
+// lgkmcnt holds 15: a count beyond it is clamped -- the wait is then stricter than needed (correct, less overlap)
+constexpr int lgkm_wait(int c, bool conv) { return lgkm_behind(c, conv) < 15 ? lgkm_behind(c, conv) : 15; }
+static_assert(RING == 4 || (lgkm_behind(NCH - 1, true) <= 15 && lgkm_behind(CR + 1, true) <= 15 && lgkm_behind(CR + 2, true) <= 15),
+              "the standard ring's waits are exact");
 
 template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
                 if constexpr (SPREAD) tr_issue_hi(b[(c + RING - 1) % RING], na0, na1);
                 else tr_issue(b[(c + RING - 1) % RING], na0, na1);
             }
-            if (ABL(8)) tr_wait<lgkm_behind(c, false)>(x); else tr_wait<lgkm_behind(c, true)>(x);
+            if (ABL(8)) tr_wait<lgkm_wait(c, false)>(x); else tr_wait<lgkm_wait(c, true)>(x);
             if (!ABL(2)) {
                 const h8 bh = cat8(x.h0, x.h1), bl = cat8(x.l0, x.l1);
                 // the cross terms go to a second accumulator so that consecutive MFMAs do not wait for each other

@@ -209,3 +209,18 @@ def test_prepare_builds_only_what_the_default_dispatch_runs(monkeypatch):
     ei2, ew2 = synthetic.sparse_traffic_graph(325, 2369, seed=1)
     assert ShiftOperator.from_edges(ei2, ew2, 325).prepare(128, cpu) == ["tile"]        # traffic-sized: the tall-tile VALU kernel
     assert ShiftOperator.from_edges(ei, ew, 2600).prepare(20, cpu) == ["csr"]             # a width no staged kernel serves
+
+
+def test_plan_cache_holds_the_pass_lists_of_long_row_operators(tmp_path, monkeypatch):
+    from sgp_amd import plancache
+    monkeypatch.setenv("SGP_AMD_CACHE", str(tmp_path))
+    n = 1400
+    ei, ew, _ = synthetic.threshold_graph(n, 330, seed=4)
+    cpu = torch.device("cpu")
+    a = ShiftOperator.from_edges(ei, ew, n).split_plan(cpu)
+    hits = plancache.stats["hits"]
+    b = ShiftOperator.from_edges(ei, ew, n).split_plan(cpu)
+    assert plancache.stats["hits"] == hits + 1 and len(a) == len(b) >= 2
+    for p, q in zip(a, b):
+        same_plan(p, q)
+        assert p.accumulate == q.accumulate

@@ -65,7 +65,15 @@ constexpr int NCH = SGP_SPLIT_NCH;           // resident 32-column chunks per wa
 constexpr int SMAX = SGP_SPLIT_SMAX;         // staged rows per tile (3 x 64 x SMAX bytes of LDS)
 constexpr int NLD = (SMAX + 16 * NW - 1) / (16 * NW);   // LDS-DMA instructions per wave and unit (16 rows each)
 constexpr int BUF = SMAX * 64;               // one staged unit: 64 B per row (fp32 in flight, then hi | lo fp16)
-constexpr int NBUF = 3;                      // landing | being converted | being multiplied
+#ifndef SGP_SPLIT_VSTAGE
+#define SGP_SPLIT_VSTAGE 0
+#endif
+// VSTAGE (wide form): a unit's pieces travel through REGISTERS instead of LDS-DMA -- global_load_dwordx4 into 4 VGPRs per
+// piece, split there, written once in the operand layout.  The LDS then moves 48 KB per unit for staging instead of 144
+// (DMA in + conversion read + write back) and needs TWO buffers (being written | being multiplied), which leaves room
+// for more staged rows per tile.  Needs 4 NLD registers for the pieces in flight: the form with 256 registers per wave.
+constexpr bool VSTAGE = SGP_SPLIT_VSTAGE != 0;
+constexpr int NBUF = VSTAGE ? 2 : 3;         // (landing |) being converted | being multiplied
 constexpr int HDR = 64;                      // ints per tile header: [NW : 2 NW] rows of every wave, [2 NW] staged rows U
 constexpr int MAXFEAT = 1024;                // scale table: 2 x feat floats behind the staging buffers
 #ifndef SGP_SPLIT_CR
@@ -73,7 +81,8 @@ constexpr int MAXFEAT = 1024;                // scale table: 2 x feat floats beh
 #endif
 constexpr int CR = SGP_SPLIT_CR;             // chunk behind which the conversion of unit u + 1 starts (>= NLD: after the staging requests)
 static_assert(BUF < 65536 - 512, "packed 16-bit transpose-read addresses");
-static_assert(CR >= NLD - 1 && CR + NLD < NCH, "conversion sits between the staging requests and the last chunk");
+static_assert(VSTAGE ? (CR >= 1 && CR + NLD <= NCH) : (CR >= NLD - 1 && CR + NLD < NCH),
+              "conversion sits between the staging requests and the last chunk");
 static_assert(NLD <= 7 && NBUF * BUF + 2 * MAXFEAT * 4 <= 160 * 1024, "three buffers and the scale table in 160 KB");
 
 #ifndef SGP_SPLIT_RING
@@ -83,7 +92,11 @@ constexpr int RING = SGP_SPLIT_RING;         // operand registers: the chunk bei
 static_assert(RING >= 2 && RING <= 4, "one to three chunks of operands in flight");
 
 // LDS operations the conversion issues behind the MFMAs of chunk c (scale + piece 0 | write 2, read 1 | ... | write 2)
-constexpr int conv_ops(int c) { return c == CR ? 2 : (c > CR && c < CR + NLD ? 3 : (c == CR + NLD ? 2 : 0)); }
+// (VSTAGE: the scale quad behind chunk CR - 1, two writes behind each of chunks CR .. CR + NLD - 1)
+constexpr int conv_ops(int c) {
+    if (VSTAGE) return (c == CR - 1 ? 1 : 0) + (c >= CR && c < CR + NLD ? 2 : 0);
+    return c == CR ? 2 : (c > CR && c < CR + NLD ? 3 : (c == CR + NLD ? 2 : 0));
+}
 // operations issued behind chunk c's operand reads when the wave waits for them: the reads of the chunks requested
 // since (4 each) and the conversion steps of the chunks in between
 #ifndef SGP_SPLIT_ACC3
@@ -183,6 +196,15 @@ __device__ __forceinline__ void dma16(unsigned voff, const void* sbase, unsigned
 // the same with a full per-lane address (two sources: own rows and halo rows)
 __device__ __forceinline__ void dma16_vaddr(const void* vaddr, unsigned lds_off) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(vaddr), "s"(lds_off) : "memory");
+}
+
+// VSTAGE: 16 B per lane into registers (scalar base + 32-bit lane offset / full per-lane address); the wait that
+// retires them names the registers, so nothing reads them before
+__device__ __forceinline__ void vload16(f32x4& d, unsigned voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void vload16_vaddr(f32x4& d, const void* vaddr) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(d) : "v"(vaddr) : "memory");
 }
 
 #ifndef SGP_SPLIT_STORE_MOD
@@ -322,24 +344,69 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
     int dt = t_begin, dsl = 0;
     auto advance = [&](int& t, int& sl) { if (++sl == a.nslice) { sl = 0; ++t; } };
 
-    // ---- prologue: units 0 and 1 requested, unit 0 converted
-    issue_dma(dt, dsl, 0); advance(dt, dsl);
-    if (n_units > 1) { issue_dma(dt, dsl, 1); advance(dt, dsl); wait_vm_n(nld); } else wait_vm<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the scale table is in place
-    {
-        f32x4 v[NLD], s4;
-        lds_read16(s4, tab_cv);
+    // VSTAGE: the pieces of the unit AFTER the one being multiplied, in registers from their request (behind that piece's
+    // conversion one unit earlier) to their conversion
+    f32x4 ld[VSTAGE ? NLD : 1];
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) lds_read16(v[i], own + i * (NW * 1024));
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4), "+v"(v[0]), "+v"(v[NLD - 1]), "+v"(v[NLD / 2]));
+    for (int i = 0; i < (VSTAGE ? NLD : 1); ++i) ld[i] = f32x4{0, 0, 0, 0};
+    auto vpiece = [&](f32x4& d, unsigned off, const float* xb, const float* xh) {
+        if constexpr (HALO) {
+            const char* b = (off & 0x80000000u) ? (const char*)xh : (const char*)xb;
+            vload16_vaddr(d, b + (off & 0x7fffffffu));
+        } else {
+            vload16(d, off, xb);
+        }
+    };
+    auto issue_loads = [&](int t, int sl) {
+        const float* xb = a.X + (long long)t * a.xbs + sl * 16;
+        const float* xh = HALO ? a.XH + (long long)t * a.xhbs + sl * 16 : nullptr;
+        // (every piece, unconditionally -- pieces past the tile's last staged row re-load row 0, as the DMA form's idle
+        // lanes do: a load under a branch makes the compiler merge the loaded registers with their old value, and it did
+        // so by COPYING a register whose load was still in flight)
+        static_for<0, (VSTAGE ? NLD : 0)>([&](auto I) {
+            constexpr int i = decltype(I)::value;
+            vpiece(ld[i], xoff[i], xb, xh);
+        });
+    };
+    if constexpr (VSTAGE) {
+        // ---- prologue: unit 0 loaded, split and written; unit 1 requested
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the scale table is in place
+        issue_loads(dt, dsl); advance(dt, dsl);
+        f32x4 s4;
+        lds_read16(s4, tab_cv);
+        wait_vm<0>();
         static_for<0, NLD>([&](auto I) {
             constexpr int i = decltype(I)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4), "+v"(ld[i]) :: "memory");
             uint2 hi, lo;
-            split4(v[i], s4, hi, lo);
+            split4(ld[i], s4, hi, lo);
             lds_write8<i * NW * 1024>(cv_off, hi); lds_write8<i * NW * 1024 + 256>(cv_off, lo);
         });
+        if (n_units <= 1) { dt = t_begin; dsl = 0; }                                 // (a single unit: its own pieces again, unused)
+        issue_loads(dt, dsl); advance(dt, dsl);
+        if (n_units <= 2) { dt = t_begin; dsl = 0; }                                 // the running pointer below never leaves the chunk
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    } else {
+        // ---- prologue: units 0 and 1 requested, unit 0 converted
+        issue_dma(dt, dsl, 0); advance(dt, dsl);
+        if (n_units > 1) { issue_dma(dt, dsl, 1); advance(dt, dsl); wait_vm_n(nld); } else wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");            // the scale table is in place
+        {
+            f32x4 v[NLD], s4;
+            lds_read16(s4, tab_cv);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) lds_read16(v[i], own + i * (NW * 1024));
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(s4), "+v"(v[0]), "+v"(v[NLD - 1]), "+v"(v[NLD / 2]));
+            static_for<0, NLD>([&](auto I) {
+                constexpr int i = decltype(I)::value;
+                uint2 hi, lo;
+                split4(v[i], s4, hi, lo);
+                lds_write8<i * NW * 1024>(cv_off, hi); lds_write8<i * NW * 1024 + 256>(cv_off, lo);
+            });
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
     }
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     int t = t_begin, sl = 0;
     unsigned cur = 0, nxt = BUF, nn = 2 * BUF;                                  // byte offsets of the three buffers
@@ -398,8 +465,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh, af[c][1], acc1, 0, 0, 0);
 #endif
             } else if constexpr (SPREAD && c + RING - 1 < NCH) tr_issue_lo(b[(c + RING - 1) % RING], na0, na1);
+            if constexpr (VSTAGE) {
+                // behind chunk CR - 1: the scale quad of unit u + 1's slice; behind chunk CR + i: piece i of unit u + 1 --
+                // requested one unit ago, so at most the nld - 1 requests made since may still be in flight (loads retire
+                // in order; stores in between only make the wait stricter) -- is split and written into the other
+                // buffer, and piece i of unit u + 2 is requested into the registers it leaves
+                if constexpr (c == CR - 1) lds_read16(s4, tab_cv + sl1 * 64);
+                if constexpr (c >= CR && c < CR + NLD) {
+                    constexpr int i = c - CR;
+                    // (no branch around any of it: in a time chunk's last units the conversion writes a buffer nobody
+                    // reads and the requests repeat the chunk's last slice)
+                    wait_vm<NLD - 1>();
+                    if constexpr (i == 0) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(s4), "+v"(ld[i]) : "n"(c + RING - 1 < NCH ? 4 : 0) : "memory");
+                    else asm volatile("" : "+v"(ld[i]) :: "memory");
+                    uint2 hi, lo;
+                    split4(ld[i], s4, hi, lo);
+                    const unsigned w = cv_off + nxt;
+                    lds_write8<i * NW * 1024>(w, hi); lds_write8<i * NW * 1024 + 256>(w, lo);
+                    vpiece(ld[i], xoff[i], xb2, xh2);
+                }
+            } else {
             if constexpr (c < NLD) { if (dma_now && c < nld) piece(xoff[c], xb2, xh2, base2 + c * (NW * 1024)); }
-            if constexpr (c >= CR && c <= CR + NLD) {
+            }
+            if constexpr (!VSTAGE && c >= CR && c <= CR + NLD) {
                 if (!ABL(8)) {
                     constexpr int i = c - CR;                  // piece to read now; piece i - 1 is split and written
                     if constexpr (i == 0) {
@@ -445,7 +533,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
         }
         stamp(u, 5);
         // advance the cursors: staging (unit u + 2 -> u + 3), result rows (u -> u + 1), scale row of unit u + 2
-        if (dma_now) {
+        if (VSTAGE ? u + 3 < n_units : dma_now) {             // (VSTAGE requests unconditionally: the pointer stays inside the chunk)
             const bool wrap = ++dsl == a.nslice;
             if (wrap) dsl = 0;
             if (!ABL(64)) xb2 += wrap ? x_wrap : 16;
@@ -458,7 +546,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void spmm_split(SplitArgs a) {
             sl1 = sl1 + 1 == a.nslice ? 0 : sl1 + 1;
             if (wrap) ++t;
         }
-        { const unsigned f = cur; cur = nxt; nxt = nn; nn = f; }
+        if constexpr (VSTAGE) { const unsigned f = cur; cur = nxt; nxt = f; }
+        else { const unsigned f = cur; cur = nxt; nxt = nn; nn = f; }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         stamp(u, 6);
     }

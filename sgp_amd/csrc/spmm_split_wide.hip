@@ -5,7 +5,8 @@
 // four waves per SIMD (sgp_spmm_split_wide_f32; same kernel source: spmm_split_impl.h).
 #define SGP_SPLIT_NW 8
 #define SGP_SPLIT_NCH 14
-#define SGP_SPLIT_SMAX 768
+#define SGP_SPLIT_SMAX 896
 #define SGP_SPLIT_CR 6
+#define SGP_SPLIT_VSTAGE 1
 #define SGP_SPLIT_NAME(x) sgp_spmm_split_wide_##x
 #include "spmm_split_impl.h"

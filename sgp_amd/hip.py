@@ -474,13 +474,30 @@ def split_profile(x, halo=None, bound=None, norm_inf=1.0, guard=True):
         t_stride = 1 if measured else max(1, B // SPLIT_SAMPLE_STEPS)
         ns = -(-B // t_stride)
         r_stride = 1 if measured else max(1, -(-(ns * N * D * 4) // SPLIT_SAMPLE_BYTES))
-        stats = col_stats(x, t_stride, r_stride=r_stride)
-        rows, all_rows = -(-N // r_stride), N
-        if halo is not None and halo.shape[1] > 0:
-            col_stats(halo, t_stride, stats, r_stride=r_stride)
-            rows += -(-halo.shape[1] // r_stride)
-            all_rows += halo.shape[1]
-        n_samples, s_eff, full = float(ns) * rows, (B * all_rows) / (float(ns) * rows), int(t_stride == 1 and r_stride == 1)
+        all_rows = N + (halo.shape[1] if halo is not None else 0)
+        sources = [x] + ([halo] if halo is not None and halo.shape[1] > 0 else [])
+        if measured or (t_stride == 1 and r_stride == 1):
+            for k, src in enumerate(sources):
+                stats = col_stats(src, 1, stats if k else None, r_stride=1)
+            n_sum = float(B) * all_rows
+        else:
+            # a strided sample of the steps before the last one ...
+            n_sum, first = 0.0, True
+            if B > 1:
+                ns = -(-(B - 1) // t_stride)
+                for src in sources:
+                    stats = col_stats(src[:B - 1], t_stride, None if first else stats, r_stride=r_stride)
+                    first = False
+                    n_sum += float(ns) * -(-src.shape[1] // r_stride)
+            # ... and EVERY row of the last step: a non-finite value that entered a recurrence anywhere in this time chunk is
+            # still there at its end (and in every hop of it), so the encoders' own operands cannot hide one from the test
+            # in an unsampled row or step (round-5 advice; 25 MB on the target line).  Any subset of the rows is a valid
+            # sample for the mean-square bound: n_samples and s_eff count what was summed.
+            for src in sources:
+                stats = col_stats(src[B - 1:], 1, None if first else stats, r_stride=1)
+                first = False
+                n_sum += float(src.shape[1])
+        n_samples, s_eff, full = n_sum, (B * all_rows) / n_sum, int(t_stride == 1 and r_stride == 1)
     _check(lib.sgp_split_prepare_f32(None if stats is None else stats.data_ptr(), n_samples, s_eff, full,
                                      None if b_in is None else b_in.data_ptr(), b_scalar, float(norm_inf), D,
                                      tab.data_ptr(), bound_out.data_ptr(), flag.data_ptr(), _stream(x)),

@@ -345,3 +345,29 @@ def test_exact_plans_are_built_only_after_a_flag_asked_for_them():
     # an accepted operand afterwards still takes the split kernel
     y3, kernel = default_hop(op, good)
     assert kernel == "spmm_split"
+
+
+def test_a_nan_that_enters_the_recurrence_between_the_sampled_steps_is_seen(monkeypatch):
+    """Round-5 advice: with an a-priori bound the admission statistics read ~8 steps.  A NaN in the encoder's INPUT at an
+    unsampled step turns that node's state NaN from there on -- the statistics now also read every row of the LAST step,
+    where it still is, so the hops fall to the exact kernel and the NaN reaches the node's graph neighbours only (the
+    reference's sparse product), not every row of the tiles that stage it."""
+    torch.manual_seed(13)
+    n, t = 2600, 40
+    ei, ew, _ = synthetic.knn_graph(n, 30, seed=3)
+    enc = sgp_amd.SGPEncoder(input_size=3, reservoir_size=64, reservoir_layers=1, leaking_rate=.9, spectral_radius=.9,
+                             density=.7, input_scaling=1., receptive_field=2, bidirectional=False, alpha_decay=False,
+                             global_attr=False)
+    x = torch.randn(t, n, 3)
+    x[37, 777, 1] = float("nan")                                   # steps 0, 5, .., 35 are the strided sample
+    ops = enc.sgp_encoder.operators(n, ei, ew)
+    y = enc.encode_device(x.cuda(), ops)
+    assert ops[0].resolved_kernel() != "spmm_split"
+    monkeypatch.setenv("SGP_TUNE", "hop=exact")
+    ops2 = enc.sgp_encoder.operators(n, ei, ew)
+    ref = enc.encode_device(x.cuda(), ops2)
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))
+    bad_rows = torch.isnan(y[:, :, 64:128]).any(2).any(0)          # hop 1: the node's out-neighbours only
+    assert 0 < int(bad_rows.sum()) < 200
+    fin = ~torch.isnan(ref)
+    assert torch.allclose(y[fin], ref[fin], rtol=1e-5, atol=1e-5)

@@ -254,8 +254,8 @@ int sgp_split_prepare_f32(const float* stats, double n_samples, double s_eff, in
  * inf in a source row (or a value that overflows fp16 after scaling: |x| above its column's bound by 4x) reaches EVERY
  * result row of every wave that stages that row, not only the row's graph neighbours as in a sparse fp32 product.
  * sgp_split_prepare_f32's admission test sees non-finite values only in the rows and steps its statistics read: all of
- * them when the bound is measured (full = 1), a sample (~8 steps, every r-th row) when the caller supplies an a-priori
- * bound.  A caller that passes a bound therefore vouches for finiteness and for the bound on the unsampled part
+ * them when the bound is measured (full = 1), a sample (~8 steps, every r-th row, plus every row of the last step -- where
+ * a value that entered a recurrence earlier still is) when the caller supplies an a-priori bound.  A caller that passes a bound therefore vouches for finiteness and for the bound on the unsampled part
  * (sgp_amd's encoders pass one only for states their own bounded-activation reservoir kernels wrote).
  * accumulate != 0: Y += A X (the later passes of an operator whose rows were cut into column segments).
  * t_chunk = time steps per workgroup (0 = chosen here). */

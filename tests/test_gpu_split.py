@@ -262,3 +262,29 @@ def test_split_partitioned_blocks_with_halo(world):
         y2 = torch.empty_like(y)
         blk.op.propagate(xo, y2, halo=halo)                         # bound measured over both sources
         close(y2, y, rtol=1e-6, atol=1e-6)
+
+
+def test_wide_form_on_partitioned_blocks_with_halo():
+    """The register-staged WIDE form (long rows: 4-pass plans, accumulating) with a halo source: the two blocks of a
+    2-way partition of a ~420-entries-per-row graph, halo rows in the all_to_all layout, 3 time chunks."""
+    torch.manual_seed(5)
+    n, t, d = 4300, 40, 128
+    ei, ew, _ = synthetic.threshold_graph(n, 420, seed=6)
+    op = graph.ShiftOperator.from_edges(ei, ew, n)
+    x = torch.tanh(torch.randn(t, n, d))
+    ref = dense_ref(op, x)
+    bounds = partition.partition_bounds(n, 2)
+    for r in range(2):
+        blk = partition.split_operator(op, bounds, r)
+        plan = blk.op.split_plan(torch.device("cuda"))
+        assert isinstance(plan, list) and len(plan) >= 2 and tuple(plan[0].afr.shape[1:3]) == (8, 14) and blk.n_halo > 0
+        xo = x[:, blk.lo:blk.hi].cuda().contiguous()
+        recv = x[:, blk.halo_global].permute(1, 0, 2).contiguous().cuda()
+        y = torch.full((t, blk.n_own, d), float("nan"), device="cuda")
+        blk.op.propagate(xo, y, halo=recv.permute(1, 0, 2), x_bound=1.0)
+        assert blk.op.resolved_kernel() == "spmm_split"
+        close(y, ref[:, blk.lo:blk.hi])
+        for _ in range(5):                                          # run to run: the same bits
+            y2 = torch.empty_like(y)
+            blk.op.propagate(xo, y2, halo=recv.permute(1, 0, 2), x_bound=1.0)
+            assert torch.equal(y2, y)

@@ -367,8 +367,16 @@ def test_a_nan_that_enters_the_recurrence_between_the_sampled_steps_is_seen():
     ref = y.clone()
     for h in range(2):
         ops[0].propagate(ref[:, :, 64 * h:64 * (h + 1)], ref[:, :, 64 * (h + 1):64 * (h + 2)], force="csr")
-    assert torch.equal(torch.isnan(y), torch.isnan(ref))
-    bad_rows = torch.isnan(y[:, :, 64:128]).any(2).any(0)          # hop 1: the node's out-neighbours only
-    assert 0 < int(bad_rows.sum()) < 200
-    fin = ~torch.isnan(ref)
+    # wherever the sparse fp32 product is NaN, so are we; beyond it at most the 16-row blocks of those rows (once a flag has
+    # come back 0 the operator plans its exact matrix-core kernel, whose dense 16-row blocks multiply explicit zeros --
+    # round-3 behaviour, test_data_beyond_the_callers_bound_and_non_finite_values; which hop that is depends on when the flag
+    # arrives), never the 221-row tiles of the split kernel
+    nan_y, nan_ref = torch.isnan(y), torch.isnan(ref)
+    assert bool((nan_ref <= nan_y).all())
+    for h in (1, 2):
+        rows_y = nan_y[:, :, 64 * h:64 * (h + 1)].any(2).any(0)
+        rows_ref = nan_ref[:, :, 64 * h:64 * (h + 1)].any(2).any(0)
+        assert 0 < int(rows_ref.sum()) <= int(rows_y.sum()) <= 16 * int(rows_ref.sum())
+    assert int(nan_y[:, :, 64:128].any(2).any(0).sum()) < 600
+    fin = ~nan_y
     assert torch.allclose(y[fin], ref[fin], rtol=1e-5, atol=1e-5)
